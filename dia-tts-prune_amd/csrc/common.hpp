@@ -1,0 +1,89 @@
+// Shared device helpers for the Dia decode-path kernels (gfx950 / CDNA4, wave64).
+//
+// Data formats used between kernels:
+//   * weight tiles   bf16 [strip = n/16][ktile = k/32][lane 0..63][8]   — the B operand of
+//                    v_mfma_f32_16x16x32_bf16: lane l holds W[k = 32*ktile + 8*(l>>4) + j][n = 16*strip + (l&15)]
+//   * activation planes  bf16 [plane 0..2][mtile = m/16][ktile][lane][8] — the A operand of the same
+//                    instruction: lane l holds X[m = 16*mtile + (l&15)][k = 32*ktile + 8*(l>>4) + j].
+//                    An fp32 activation v travels as three bf16 planes hi+mid+lo == v (24 significand
+//                    bits), so bf16 MFMA products against bf16 weights are exact and accumulate in fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint16_t bf16_raw;
+
+#define DIA_WAVE 64
+#define DIA_NPLANES 3
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+
+// v == hi + mid + lo, each bf16 (round-to-nearest-even at every stage)
+__device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = (__bf16)v;
+  float r = v - (float)hi;
+  mid = (__bf16)r;
+  float r2 = r - (float)mid;
+  lo = (__bf16)r2;
+}
+
+// element offset of the 8-element fragment holding X[m][k0..k0+7] (k0 % 8 == 0) inside one plane
+__device__ __forceinline__ long plane_frag_off(int m, int k0, int ktiles) {
+  int mt = m >> 4, kt = k0 >> 5, kq = (k0 & 31) >> 3;
+  int lane = (m & 15) + 16 * kq;
+  return (((long)mt * ktiles + kt) * 64 + lane) * 8;
+}
+
+// write 8 consecutive-k activations of row m as three plane fragments (16 B each)
+__device__ __forceinline__ void emit_planes8(bf16_raw* P, long plane_stride, int ktiles, int m, int k0,
+                                             const float* v) {
+  bf16x8 h, mi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 a, b, c;
+    split3(v[j], a, b, c);
+    h[j] = a; mi[j] = b; lo[j] = c;
+  }
+  long off = plane_frag_off(m, k0, ktiles);
+  *reinterpret_cast<bf16x8*>(P + off) = h;
+  *reinterpret_cast<bf16x8*>(P + plane_stride + off) = mi;
+  *reinterpret_cast<bf16x8*>(P + 2 * plane_stride + off) = lo;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <typename T> struct KVElem;
+template <> struct KVElem<float> {
+  static __device__ __forceinline__ void load8(const float* p, float* o) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+  static __device__ __forceinline__ float round(float v) { return v; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct KVElem<bf16_raw> {
+  static __device__ __forceinline__ void load8(const bf16_raw* p, float* o) {
+    uint4 u = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xFFFF0000u);
+    o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xFFFF0000u);
+    o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xFFFF0000u);
+  }
+  static __device__ __forceinline__ float round(float v) { return (float)(__bf16)v; }
+  static __device__ __forceinline__ void store(bf16_raw* p, float v) {
+    __bf16 b = (__bf16)v;
+    *p = *reinterpret_cast<bf16_raw*>(&b);
+  }
+};

@@ -1,0 +1,182 @@
+// Decode-step sequencer: chains the kernels of one autoregressive step (reference
+// Decoder.decode_step, dia/layers.py:671-720, driven by the loop at dia/model.py:748-807) on one HIP
+// stream and replays it as a hipGraph.  The engine allocates nothing: every buffer comes from the
+// caller (PyTorch-ROCm tensors used as storage).  All per-step variables (current step, KV length,
+// EOS state) live in device memory, so the captured graph is static and the host never syncs
+// inside the loop.
+#include "common.hpp"
+#include "../../include/dia_hip.h"
+#include "errors.hpp"
+#include <vector>
+
+struct dia_engine {
+  dia_engine_desc d;
+  std::vector<dia_dec_layer> layers;
+  hipStream_t stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int launches = 0;
+};
+
+static int kernels_init_once() {
+  static int rc = -100;
+  if (rc == -100) {
+    rc = dia_attn_init();
+    if (rc == DIA_OK) rc = dia_sample_init();
+  }
+  return rc;
+}
+
+static int enqueue_step(dia_engine* e, bool with_sampler) {
+  const dia_engine_desc& d = e->d;
+  void* st = (void*)e->stream;
+  const int R = 2 * d.B;
+  const int xkt = d.D / 32;                                       // k-tiles of the x planes
+  const int akt = (max(d.q_heads, d.cq_heads) * 128) / 32;        // k-tiles of the attention planes
+  const int hkt = d.F / 32;
+  const long mt = d.rows_pad / 16;
+  const long xs = mt * xkt * 512, as = mt * akt * 512, hs = mt * hkt * 512;   // plane strides (elements)
+  const int nqkv = (d.q_heads + 2 * d.kv_heads) * 128;
+  int n = 0, rc;
+
+  for (int l = 0; l < d.n_layer; ++l) {
+    const dia_dec_layer& L = e->layers[l];
+    dia_gemm_args g = {};
+    // q/k/v projection of the pre-SA-normed row (layers.py:541, 273-275)
+    g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
+    g.W = L.w_qkv; g.KT = L.kt_qkv; g.nstrips = L.ns_qkv; g.epi = DIA_EPI_SCALE_STORE;
+    g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
+    g.out = d.qkv; g.ldo = nqkv;
+    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+
+    dia_attn_args a = {};
+    a.mode = DIA_ATTN_SELF; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.kv_heads; a.group = d.q_heads / d.kv_heads;
+    a.n_rows = R; a.kv_cap = d.T; a.q = d.qkv; a.ldq = nqkv; a.q_off = 0; a.k_off = d.q_heads * 128;
+    a.v_off = (d.q_heads + d.kv_heads) * 128; a.kc = L.k_self; a.vc = L.v_self; a.cur = d.sample.cur;
+    a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
+    if ((rc = dia_attn(&a, st))) return rc; ++n;
+
+    // o_proj + residual; emits the pre-CA-normed planes (layers.py:341-343, 555, 560)
+    g = {};
+    g.A = d.planes_a; g.a_plane_stride = as; g.a_ktiles = akt; g.M = R;
+    g.W = L.w_o; g.KT = L.kt_o; g.nstrips = L.ns_o; g.epi = DIA_EPI_RESID_EMIT;
+    g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_ca;
+    g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
+    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+
+    // cross-attention query (layers.py:273, 278)
+    g = {};
+    g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
+    g.W = L.w_cq; g.KT = L.kt_cq; g.nstrips = L.ns_cq; g.epi = DIA_EPI_SCALE_STORE;
+    g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
+    g.out = d.qc; g.ldo = d.cq_heads * 128;
+    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+
+    a = {};
+    a.mode = DIA_ATTN_CROSS; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.cq_heads; a.group = 1;
+    a.n_rows = d.B; a.kv_cap = d.S; a.q = d.qc; a.ldq = d.cq_heads * 128; a.q_off = 0;
+    a.kc = L.k_cross; a.vc = L.v_cross; a.cur = d.sample.cur; a.len = d.text_len;
+    a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
+    if ((rc = dia_attn(&a, st))) return rc; ++n;
+
+    g = {};
+    g.A = d.planes_a; g.a_plane_stride = as; g.a_ktiles = akt; g.M = R;
+    g.W = L.w_co; g.KT = L.kt_co; g.nstrips = L.ns_co; g.epi = DIA_EPI_RESID_EMIT;
+    g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_mlp;
+    g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
+    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+
+    // SwiGLU MLP (layers.py:95-104)
+    g = {};
+    g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
+    g.W = L.w_wi; g.KT = L.kt_wi; g.nstrips = L.ns_wi; g.epi = DIA_EPI_SWIGLU_EMIT;
+    g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
+    g.P = d.planes_h; g.p_plane_stride = hs; g.p_ktiles = hkt;
+    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+
+    g = {};
+    g.A = d.planes_h; g.a_plane_stride = hs; g.a_ktiles = hkt; g.M = R;
+    g.W = L.w_wo; g.KT = L.kt_wo; g.nstrips = L.ns_wo; g.epi = DIA_EPI_RESID_EMIT;
+    g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D;
+    g.gnext = (l + 1 < d.n_layer) ? e->layers[l + 1].g_sa : d.g_final;
+    g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
+    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+  }
+  // final norm + logits (layers.py:714-717)
+  dia_gemm_args g = {};
+  g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
+  g.W = d.w_logits; g.KT = d.kt_logits; g.nstrips = d.ns_logits; g.epi = DIA_EPI_SCALE_STORE;
+  g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
+  g.out = d.logits; g.ldo = d.ld_logits;
+  if ((rc = dia_gemm(&g, st))) return rc; ++n;
+  if (with_sampler) {
+    if ((rc = dia_sample(&d.sample, st))) return rc; ++n;
+  }
+  e->launches = n;
+  return DIA_OK;
+}
+
+extern "C" int dia_engine_create(const dia_engine_desc* d, void* stream, dia_engine** out) {
+  if (!d || !out || !d->layers) return dia_fail(DIA_E_ARG, "dia_engine_create: null argument");
+  if (d->n_layer <= 0 || d->B <= 0) return dia_fail(DIA_E_ARG, "dia_engine_create: empty model");
+  if (d->D % 32 != 0 || d->F % 32 != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: D and F must be multiples of 32");
+  if (d->rows_pad < 2 * d->B || d->rows_pad % 16 != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: rows_pad must be 16*ceil(2B/16)");
+  if (d->q_heads % d->kv_heads != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: q_heads % kv_heads != 0");
+  if (!d->x || !d->planes_x || !d->planes_a || !d->planes_h || !d->ssq || !d->qkv || !d->qc || !d->logits || !d->cos_t ||
+      !d->sin_t || !d->text_len || !d->w_logits || !d->g_final)
+    return dia_fail(DIA_E_ARG, "dia_engine_create: missing buffer");
+  int rc = kernels_init_once();
+  if (rc) return rc;
+  dia_engine* e = new dia_engine();
+  e->d = *d;
+  e->layers.assign(d->layers, d->layers + d->n_layer);
+  e->d.layers = e->layers.data();
+  e->stream = (hipStream_t)stream;
+  *out = e;
+  return DIA_OK;
+}
+
+extern "C" int dia_engine_destroy(dia_engine* e) {
+  if (!e) return DIA_OK;
+  if (e->exec) (void)hipGraphExecDestroy(e->exec);
+  if (e->graph) (void)hipGraphDestroy(e->graph);
+  delete e;
+  return DIA_OK;
+}
+
+extern "C" int dia_engine_decode(dia_engine* e, int n_steps, int use_graph) {
+  if (!e || n_steps < 0) return dia_fail(DIA_E_ARG, "dia_engine_decode: bad argument");
+  if (!use_graph) {
+    for (int i = 0; i < n_steps; ++i) {
+      int rc = enqueue_step(e, true);
+      if (rc) return rc;
+    }
+    return DIA_OK;
+  }
+  if (!e->exec) {
+    if (e->stream == nullptr) return dia_fail(DIA_E_STATE, "dia_engine_decode: graph capture needs a non-default stream");
+    hipError_t he = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+    if (he != hipSuccess) return dia_fail_hip(he, "hipStreamBeginCapture");
+    int rc = enqueue_step(e, true);
+    he = hipStreamEndCapture(e->stream, &e->graph);
+    if (rc) return rc;
+    if (he != hipSuccess) return dia_fail_hip(he, "hipStreamEndCapture");
+    he = hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0);
+    if (he != hipSuccess) return dia_fail_hip(he, "hipGraphInstantiate");
+  }
+  for (int i = 0; i < n_steps; ++i) {
+    hipError_t he = hipGraphLaunch(e->exec, e->stream);
+    if (he != hipSuccess) return dia_fail_hip(he, "hipGraphLaunch");
+  }
+  return DIA_OK;
+}
+
+extern "C" int dia_engine_step_logits_only(dia_engine* e) {
+  if (!e) return dia_fail(DIA_E_ARG, "dia_engine_step_logits_only: null engine");
+  return enqueue_step(e, false);
+}
+
+extern "C" int dia_engine_launches_per_step(const dia_engine* e) {
+  if (!e) return dia_fail(DIA_E_ARG, "null engine");
+  return e->d.n_layer * 8 + 2;
+}

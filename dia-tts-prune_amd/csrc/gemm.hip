@@ -1,0 +1,275 @@
+// Skinny GEMM for the decode path: out[M][N] = X[M][K] . W[K][N], M small (2..64 rows per launch
+// group), W streamed from HBM exactly once per launch.
+//
+// Replaces DenseGeneral.forward (reference dia/layers.py:55-66, torch.tensordot) plus, via the
+// epilogues, RMSNorm scaling, residual add, SwiGLU and the cross-K/V RoPE + cache store.
+//
+// Mapping (CDNA4): one workgroup owns one 16-column strip of W and all of K; its NW waves split K
+// into contiguous ranges of KPW k-tiles.  A k-tile of the strip is one contiguous 1 KiB block
+// (64 lanes x 16 B) that is loaded straight into the B operand of v_mfma_f32_16x16x32_bf16 — no
+// LDS staging, no conversion (guide §5 'GEMV / M <= 16 decode weights').  All B loads of a wave
+// are issued before the first use, so a 16-wave workgroup keeps up to 64 KiB in flight.  X arrives
+// as three bf16 planes (hi+mid+lo == fp32 value); three MFMAs per k-tile accumulate them into one
+// fp32 accumulator, which makes the product exact w.r.t. the fp32 activations of the reference.
+// Cross-wave (split-K) partials are summed through LDS in a fixed order: results are
+// bit-reproducible run to run.
+#include "common.hpp"
+#include "../../include/dia_hip.h"
+#include "errors.hpp"
+
+namespace {
+
+struct GemmK {
+  const bf16_raw* A; long a_plane_stride; int a_ktiles; int M;
+  const bf16_raw* W; int KT; int nstrips; int epi;
+  const float* ssq_in; int ssq_in_n; int ssq_ld; float inv_d; float eps;
+  float* out; int ldo;
+  const float* gnext;
+  bf16_raw* P; long p_plane_stride; int p_ktiles;
+  float* ssq_out;
+  void* kc; void* vc; int kv_dtype; int kv_heads; int kv_cap; int kv_batch_index;
+  const float* cos_t; const float* sin_t;
+};
+
+__device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v) {
+  if (dtype == DIA_KV_F32) reinterpret_cast<float*>(base)[idx] = v;
+  else KVElem<bf16_raw>::store(reinterpret_cast<bf16_raw*>(base) + idx, v);
+}
+
+template <int MT, int NW, int KPW>
+__global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][MT][64]
+  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * MT * 64);   // [MT][16][17]
+  float* inv_s = tile + MT * 16 * 17;                                      // [MT*16]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int strip = blockIdx.x;
+  const int mt0 = blockIdx.y * MT;                 // first m-tile of this group
+  const int kpw = (KPW > 0) ? KPW : (p.KT + NW - 1) / NW;
+  const int kt0 = w * kpw;
+
+  f32x4 acc[MT];
+  int mtile[MT];   // rows >= M are computed on whatever the (clamped) tile holds and never stored
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mtile[i] = min(mt0 + i, (p.M - 1) >> 4);
+  }
+
+  const bf16x8* Wt = reinterpret_cast<const bf16x8*>(p.W) + ((long)strip * p.KT) * 64 + lane;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  if constexpr (KPW > 0) {
+    bf16x8 b[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) b[i] = __builtin_nontemporal_load(Wt + (long)(kt0 + i) * 64);
+    __builtin_amdgcn_sched_barrier(0);   // every HBM load of this wave is in flight before the L2-resident A loads
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bf16x8* Af = reinterpret_cast<const bf16x8*>(p.A) + ((long)mtile[mt] * p.a_ktiles + (kt0 + i)) * 64 + lane;
+#pragma unroll
+        for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+          bf16x8 a = Af[(pl * p.a_plane_stride) >> 3];
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    const int kt1 = min(kt0 + kpw, p.KT);
+    for (int kt = kt0; kt < kt1; kt += 4) {
+      bf16x8 b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = (kt + i < kt1) ? __builtin_nontemporal_load(Wt + (long)(kt + i) * 64) : zero8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (kt + i < kt1) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8* Af = reinterpret_cast<const bf16x8*>(p.A) + ((long)mtile[mt] * p.a_ktiles + (kt + i)) * 64 + lane;
+#pragma unroll
+            for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+              bf16x8 a = Af[(pl * p.a_plane_stride) >> 3];
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- split-K partials -> LDS, fixed-order sum by wave 0..MT-1
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) red[(w * MT + mt) * 64 + lane] = acc[mt];
+
+  // row scales while the partials land (threads 0 .. MT*16*8-1: 8 threads per row)
+  for (int t = tid; t < MT * 128; t += NW * 64) {
+    const int r = t >> 3, part = t & 7;
+    const int row = mt0 * 16 + r;
+    float s = 0.f;
+    if (p.ssq_in != nullptr && row < p.M)
+      for (int i = part; i < p.ssq_in_n; i += 8) s += p.ssq_in[(long)i * p.ssq_ld + row];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (part == 0) inv_s[r] = (p.ssq_in != nullptr) ? rsqrtf(s * p.inv_d + p.eps) : 1.0f;
+  }
+  __syncthreads();
+  if (tid < MT * 64) {
+    const int mt = tid >> 6;
+    f32x4 s = red[(0 * MT + mt) * 64 + lane];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {
+      f32x4 t = red[(ww * MT + mt) * 64 + lane];
+      s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    }
+    const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(mt * 16 + r0 + r) * 17 + col] = s[r];
+  }
+  __syncthreads();
+
+  // ---- epilogue: MT*32 threads, each 8 consecutive columns of one row
+  if (tid >= MT * 32) return;
+  const int mt = tid >> 5, r = (tid >> 1) & 15, half = tid & 1;
+  const int m = (mt0 + mt) * 16 + r;
+  const float* trow = tile + (mt * 16 + r) * 17;
+  const float inv = inv_s[mt * 16 + r];
+  const int n0 = strip * 16 + half * 8;
+  const bool live = m < p.M;
+
+  if (p.epi == DIA_EPI_SCALE_STORE) {
+    if (!live) return;
+    float4 a = {trow[half * 8 + 0] * inv, trow[half * 8 + 1] * inv, trow[half * 8 + 2] * inv, trow[half * 8 + 3] * inv};
+    float4 b = {trow[half * 8 + 4] * inv, trow[half * 8 + 5] * inv, trow[half * 8 + 6] * inv, trow[half * 8 + 7] * inv};
+    float* o = p.out + (long)m * p.ldo + n0;
+    *reinterpret_cast<float4*>(o) = a;
+    *reinterpret_cast<float4*>(o + 4) = b;
+  } else if (p.epi == DIA_EPI_RESID_EMIT) {
+    float v[8];
+    float ss = 0.f;
+    if (live) {
+      float* o = p.out + (long)m * p.ldo + n0;
+      float4 xa = *reinterpret_cast<float4*>(o), xb = *reinterpret_cast<float4*>(o + 4);
+      v[0] = xa.x + trow[half * 8 + 0]; v[1] = xa.y + trow[half * 8 + 1];
+      v[2] = xa.z + trow[half * 8 + 2]; v[3] = xa.w + trow[half * 8 + 3];
+      v[4] = xb.x + trow[half * 8 + 4]; v[5] = xb.y + trow[half * 8 + 5];
+      v[6] = xb.z + trow[half * 8 + 6]; v[7] = xb.w + trow[half * 8 + 7];
+      *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+      if (p.gnext != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= p.gnext[n0 + j];
+      }
+      emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, m, n0, v);
+    }
+    float other = __shfl_xor(ss, 1, 64);
+    if (half == 0 && live) p.ssq_out[(long)strip * p.ssq_ld + m] = ss + other;
+  } else if (p.epi == DIA_EPI_SWIGLU_EMIT) {
+    if (!live || half != 0) return;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float g = trow[j] * inv, u = trow[8 + j] * inv;
+      v[j] = (g / (1.0f + expf(-g))) * u;
+    }
+    emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, m, strip * 8, v);
+  } else {  // DIA_EPI_CROSSKV: strips [0, heads*8) hold K as RoPE pairs (d, d+64), the rest hold V
+    if (!live) return;
+    const int nk = p.kv_heads * 8;
+    if (strip < nk) {
+      const int head = strip >> 3, i0 = (strip & 7) * 8 + half * 4;
+      const long base = (((long)p.kv_batch_index * p.kv_heads + head) * p.kv_cap + m) * 128;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = i0 + t;
+        const float x1 = trow[half * 8 + 2 * t] * inv, x2 = trow[half * 8 + 2 * t + 1] * inv;
+        const float c = p.cos_t[(long)m * 64 + i], s = p.sin_t[(long)m * 64 + i];
+        kv_store(p.kc, p.kv_dtype, base + i, x1 * c - x2 * s);
+        kv_store(p.kc, p.kv_dtype, base + i + 64, x1 * s + x2 * c);
+      }
+    } else {
+      const int sv = strip - nk, head = sv >> 3, d0 = (sv & 7) * 16 + half * 8;
+      const long base = (((long)p.kv_batch_index * p.kv_heads + head) * p.kv_cap + m) * 128 + d0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kv_store(p.vc, p.kv_dtype, base + j, trow[half * 8 + j] * inv);
+    }
+  }
+}
+
+template <int MT, int NW, int KPW>
+int launch(const GemmK& k, int mgroups, hipStream_t st) {
+  size_t smem = sizeof(f32x4) * NW * MT * 64 + sizeof(float) * (MT * 16 * 17 + MT * 16);
+  hipLaunchKernelGGL((k_gemm<MT, NW, KPW>), dim3(k.nstrips, mgroups), dim3(NW * 64), smem, st, k);
+  return dia_check_launch("k_gemm");
+}
+
+template <int MT, int NW>
+int launch_kpw(const GemmK& k, int mgroups, hipStream_t st) {
+  if (k.KT % NW == 0) {
+    switch (k.KT / NW) {
+      case 2: return launch<MT, NW, 2>(k, mgroups, st);
+      case 4: return launch<MT, NW, 4>(k, mgroups, st);
+      case 8: return launch<MT, NW, 8>(k, mgroups, st);
+      case 16: return launch<MT, NW, 16>(k, mgroups, st);
+      default: break;
+    }
+  }
+  return launch<MT, NW, 0>(k, mgroups, st);
+}
+
+template <int MT>
+int launch_nw(const GemmK& k, int nw, int mgroups, hipStream_t st) {
+  switch (nw) {
+    case 4: return launch_kpw<MT, 4>(k, mgroups, st);
+    case 8: return launch_kpw<MT, 8>(k, mgroups, st);
+    case 16: return launch_kpw<MT, 16>(k, mgroups, st);
+    default: return dia_fail(DIA_E_ARG, "dia_gemm: nw must be 4, 8 or 16");
+  }
+}
+
+}  // namespace
+
+extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
+  if (!a || !a->A || !a->W) return dia_fail(DIA_E_ARG, "dia_gemm: null argument");
+  if (a->M <= 0 || a->KT <= 0 || a->nstrips <= 0) return dia_fail(DIA_E_ARG, "dia_gemm: empty problem");
+  if (a->KT > a->a_ktiles) return dia_fail(DIA_E_ARG, "dia_gemm: weight K exceeds the plane layout's K");
+  if (a->a_plane_stride % 8 != 0 || a->p_plane_stride % 8 != 0) return dia_fail(DIA_E_ARG, "dia_gemm: plane stride must be a multiple of 8");
+  if ((a->epi == DIA_EPI_SCALE_STORE || a->epi == DIA_EPI_RESID_EMIT) && (!a->out || a->ldo < a->nstrips * 16 || a->ldo % 4 != 0))
+    return dia_fail(DIA_E_ARG, "dia_gemm: output leading dimension too small");
+  if ((a->epi == DIA_EPI_RESID_EMIT) && (!a->P || !a->ssq_out || a->p_ktiles * 32 < a->nstrips * 16))
+    return dia_fail(DIA_E_ARG, "dia_gemm: RESID_EMIT needs planes and ssq_out covering N");
+  if ((a->epi == DIA_EPI_SWIGLU_EMIT) && (!a->P || a->p_ktiles * 32 < a->nstrips * 8))
+    return dia_fail(DIA_E_ARG, "dia_gemm: SWIGLU_EMIT needs planes covering N/2");
+  if (a->epi == DIA_EPI_CROSSKV && (!a->kc || !a->vc || !a->cos_t || !a->sin_t || a->nstrips != a->kv_heads * 16 || a->M > a->kv_cap))
+    return dia_fail(DIA_E_ARG, "dia_gemm: CROSSKV shape mismatch");
+  if (a->epi < 0 || a->epi > DIA_EPI_CROSSKV) return dia_fail(DIA_E_ARG, "dia_gemm: unknown epilogue");
+  if (a->ssq_in && a->ssq_ld < ((a->M + 15) / 16) * 16) return dia_fail(DIA_E_ARG, "dia_gemm: ssq_ld smaller than padded rows");
+
+  GemmK k;
+  k.A = (const bf16_raw*)a->A; k.a_plane_stride = a->a_plane_stride; k.a_ktiles = a->a_ktiles; k.M = a->M;
+  k.W = (const bf16_raw*)a->W; k.KT = a->KT; k.nstrips = a->nstrips; k.epi = a->epi;
+  k.ssq_in = a->ssq_in; k.ssq_in_n = a->ssq_in_n; k.ssq_ld = a->ssq_ld; k.inv_d = a->inv_d; k.eps = a->eps;
+  k.out = a->out; k.ldo = a->ldo; k.gnext = a->gnext;
+  k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles; k.ssq_out = a->ssq_out;
+  k.kc = a->kc; k.vc = a->vc; k.kv_dtype = a->kv_dtype; k.kv_heads = a->kv_heads; k.kv_cap = a->kv_cap;
+  k.kv_batch_index = a->kv_batch_index; k.cos_t = a->cos_t; k.sin_t = a->sin_t;
+
+  int nw = a->nw;
+  if (nw == 0) {
+    // many strips -> few fat waves (deep load queues); few strips -> many waves per strip
+    if (a->nstrips >= 512 && a->KT % 4 == 0 && a->KT / 4 <= 16) nw = 4;
+    else if (a->KT % 16 == 0) nw = 16;
+    else if (a->KT % 8 == 0) nw = 8;
+    else nw = 4;
+  }
+  const int mtiles = (a->M + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  if (mtiles == 1) return launch_nw<1>(k, nw, 1, st);
+  if (mtiles == 2) return launch_nw<2>(k, nw, 1, st);
+  return launch_nw<4>(k, nw, (mtiles + 3) / 4, st);
+}

@@ -1,0 +1,416 @@
+"""Host side of the MI355X decode path: weight residency, prefill, and the decode loop.
+
+Everything numerical happens in ``libdia_hip.so``; torch tensors are storage (``data_ptr()``),
+streams and events.  The call sequence mirrors the reference's ``Dia._prepare_generation``
+(dia/model.py:355-427) and the ``while`` loop of ``Dia.generate`` (model.py:748-807):
+
+  prefill(b):  text ids -> encoder (12 layers) -> per-decoder-layer cross K/V     [model.py:382-397]
+  decode:      one hipGraph replay per step; token state machine on the device     [model.py:748-807]
+
+Rows of every activation buffer are ordered ``2*b + {0: uncond, 1: cond}`` (model.py:362).  The
+uncond row never sees text, so the encoder runs on the packed non-pad tokens of
+the cond row only — exact, SURVEY.md App. B3.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import binding as hb
+from . import layout as lay
+from .config import DiaConfig
+
+HEAD_DIM = 128
+
+
+def _ceil(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class TiledW:
+    t: torch.Tensor
+    kt: int
+    ns: int
+
+    @property
+    def nbytes(self) -> int:
+        return self.t.numel() * 2
+
+
+class DeviceWeights:
+    """Checkpoint -> kernel layouts, resident in HBM (bf16 tiles; norms / embeddings fp32)."""
+
+    def __init__(self, cfg: DiaConfig, sd: Dict[str, torch.Tensor], device: torch.device):
+        m, e, d = cfg.model, cfg.model.encoder, cfg.model.decoder
+        if d.gqa_head_dim != HEAD_DIM or d.cross_head_dim != HEAD_DIM or e.head_dim != HEAD_DIM:
+            raise hb.DiaHipError("the HIP attention kernels are built for head_dim 128 (Dia-1.6B)")
+        if d.n_embd % 32 or d.n_hidden % 32 or e.n_embd % 32 or e.n_hidden % 32:
+            raise hb.DiaHipError("embedding / hidden sizes must be multiples of 32")
+        self.cfg, self.device = cfg, device
+
+        def dev(name):
+            return sd[name].to(device=device, dtype=torch.float32)
+
+        def tile(w2d) -> TiledW:
+            t, kt, ns = lay.tile_weight(w2d)
+            return TiledW(t, kt, ns)
+
+        perm = lay.rope_pair_perm(HEAD_DIM).to(device)
+        self.enc_emb = dev("encoder.embedding.weight").contiguous()
+        self.enc_layers = []
+        for i in range(e.n_layer):
+            p = f"encoder.layers.{i}."
+            E = e.n_embd
+            qkv = torch.cat([dev(p + f"self_attention.{n}_proj.weight").reshape(E, -1) for n in "qkv"], dim=1)
+            self.enc_layers.append(dict(
+                g_sa=dev(p + "pre_sa_norm.weight").contiguous(), g_mlp=dev(p + "post_sa_norm.weight").contiguous(),
+                qkv=tile(qkv), o=tile(dev(p + "self_attention.o_proj.weight").reshape(-1, E)),
+                wi=tile(lay.interleave_gate_up(dev(p + "mlp.wi_fused.weight"))), wo=tile(dev(p + "mlp.wo.weight")),
+            ))
+        self.enc_norm = dev("encoder.norm.weight").contiguous()
+        self.dec_emb = torch.stack([dev(f"decoder.embeddings.{c}.weight") for c in range(cfg.data.channels)]).contiguous()
+        self.dec_layers = []
+        D = d.n_embd
+        for i in range(d.n_layer):
+            p = f"decoder.layers.{i}."
+            qkv = torch.cat([dev(p + f"self_attention.{n}_proj.weight").reshape(D, -1) for n in "qkv"], dim=1)
+            ck = dev(p + "cross_attention.k_proj.weight")[:, :, perm].reshape(e.n_embd, -1)
+            cv = dev(p + "cross_attention.v_proj.weight").reshape(e.n_embd, -1)
+            self.dec_layers.append(dict(
+                g_sa=dev(p + "pre_sa_norm.weight").contiguous(), g_ca=dev(p + "pre_ca_norm.weight").contiguous(),
+                g_mlp=dev(p + "pre_mlp_norm.weight").contiguous(),
+                qkv=tile(qkv), o=tile(dev(p + "self_attention.o_proj.weight").reshape(-1, D)),
+                cq=tile(dev(p + "cross_attention.q_proj.weight").reshape(D, -1)),
+                co=tile(dev(p + "cross_attention.o_proj.weight").reshape(-1, D)),
+                ckv=tile(torch.cat([ck, cv], dim=1)),
+                wi=tile(lay.interleave_gate_up(dev(p + "mlp.wi_fused.weight"))), wo=tile(dev(p + "mlp.wo.weight")),
+            ))
+        self.dec_norm = dev("decoder.norm.weight").contiguous()
+        self.logits = tile(dev("decoder.logits_dense.weight").reshape(D, -1))
+        npos = max(cfg.data.audio_length, cfg.data.text_length) + 1
+        cos, sin = lay.rope_tables(npos, HEAD_DIM, m.rope_min_timescale, m.rope_max_timescale)
+        self.cos_t, self.sin_t = cos.to(device), sin.to(device)
+
+    def decode_weight_bytes(self) -> int:
+        """bf16 bytes one decode step streams (SURVEY.md §8d 'W'): every decoder matrix except the
+        prefill-only cross K/V projections, plus the logits head."""
+        n = self.logits.nbytes
+        for L in self.dec_layers:
+            n += sum(L[k].nbytes for k in ("qkv", "o", "cq", "co", "wi", "wo"))
+        return n
+
+
+@dataclass
+class UtteranceResult:
+    tokens: np.ndarray          # int32 [T, C] token buffer (DecoderOutput.generated_tokens)
+    codes: np.ndarray           # rows [prefill_step : last_step+1]   (model.py:831)
+    last_step: int
+    preds: np.ndarray           # int32 [T, C] raw samples per step row (before the EOS state machine)
+    text_len: int
+
+
+class DecodeSession:
+    """Buffers + engine for one batch of utterances."""
+
+    def __init__(self, w: DeviceWeights, text_ids: Sequence[np.ndarray], *, kv_dtype: str = "bf16",
+                 max_tokens: Optional[int] = None, cfg_scale: float = 3.0, temperature: float = 1.3,
+                 top_p: float = 0.95, top_k: int = 35, seeds: Optional[Sequence[Optional[int]]] = None,
+                 noise: Optional[torch.Tensor] = None, ignore_eos: bool = False,
+                 teacher_tokens: Optional[Sequence[np.ndarray]] = None, stream: Optional[torch.cuda.Stream] = None,
+                 s_cap: Optional[int] = None):
+        cfg, dev = w.cfg, w.device
+        self.w, self.cfg, self.dev = w, cfg, dev
+        d, da = cfg.model.decoder, cfg.data
+        self.B = B = len(text_ids)
+        self.R = 2 * B
+        self.rows_pad = _ceil(self.R, 16)
+        self.T = da.audio_length
+        self.C, self.V, self.D, self.F = da.channels, cfg.model.tgt_vocab_size, d.n_embd, d.n_hidden
+        self.max_tokens = self.T if max_tokens is None else int(max_tokens)
+        if not (2 <= self.max_tokens <= self.T):
+            raise ValueError(f"max_tokens must be in [2, {self.T}]")
+        self.kv_code = {"f32": hb.KV_F32, "float32": hb.KV_F32, "bf16": hb.KV_BF16, "bfloat16": hb.KV_BF16}[kv_dtype]
+        kvt = torch.float32 if self.kv_code == hb.KV_F32 else torch.bfloat16
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.lens = [int(len(t)) for t in text_ids]
+        self.S = s_cap if s_cap is not None else max(16, _ceil(max(self.lens + [1]), 16))
+        if self.S > da.text_length and s_cap is None:
+            self.S = da.text_length
+        self.text_ids = [np.asarray(t, dtype=np.int32) for t in text_ids]
+        self.teacher = teacher_tokens is not None
+        self.ignore_eos = ignore_eos
+        md = max(da.delay_pattern)
+        self.max_delay = md
+
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        mt = self.rows_pad // 16
+        self.xkt, self.akt, self.hkt = self.D // 32, max(d.gqa_query_heads, d.cross_query_heads) * HEAD_DIM // 32, self.F // 32
+        self.x = z(self.rows_pad, self.D)
+        self.planes_x = z(3, mt, self.xkt, 64, 8, dt=torch.bfloat16)
+        self.planes_a = z(3, mt, self.akt, 64, 8, dt=torch.bfloat16)
+        self.planes_h = z(3, mt, self.hkt, 64, 8, dt=torch.bfloat16)
+        self.ssq = z(self.D // 16, self.rows_pad)
+        self.nqkv = (d.gqa_query_heads + 2 * d.kv_heads) * HEAD_DIM
+        self.qkv = z(self.rows_pad, self.nqkv)
+        self.qc = z(self.rows_pad, d.cross_query_heads * HEAD_DIM)
+        self.ld_logits = w.logits.ns * 16
+        self.logits = z(self.rows_pad, self.ld_logits)
+        self.k_self = [z(self.R, d.kv_heads, self.T, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
+        self.v_self = [z(self.R, d.kv_heads, self.T, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
+        self.k_cross = [z(B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
+        self.v_cross = [z(B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
+        self.text_len = torch.tensor(self.lens, dtype=torch.int32, device=dev)
+
+        # token buffer + state machine (state.py:178-208; model.py:736-741)
+        from .tokens import delayed_prefill
+        prefill, pstep = delayed_prefill(cfg)
+        tok = np.full((B, self.T, self.C), -1, dtype=np.int32)
+        tok[:, : prefill.shape[0]] = prefill[None]
+        if self.teacher:
+            for b in range(B):
+                tt = np.asarray(teacher_tokens[b], dtype=np.int32)
+                tok[b, : tt.shape[0]] = tt
+        self.prefill_step = pstep
+        self.tokens = torch.from_numpy(tok).to(dev)
+        self.pred = torch.full((B, self.T, self.C), -1, dtype=torch.int32, device=dev)
+        self.cur = torch.full((B,), pstep, dtype=torch.int32, device=dev)
+        fsm = np.zeros((B, 8), dtype=np.int32)
+        fsm[:, 1] = -1
+        fsm[:, 2] = md
+        self.fsm = torch.from_numpy(fsm).to(dev)
+        self.delay = torch.tensor(list(da.delay_pattern), dtype=torch.int32, device=dev)
+
+        # Exp(1) variates for the multinomial draw: the reference's generator stream after
+        # torch.manual_seed(seed) (model.py:679-683), one [C,V] draw per step, drawn in one batch
+        self.noise_steps = self.max_tokens - 1
+        if temperature != 0.0:
+            if noise is not None:
+                nz = noise.to(torch.float32)
+                if tuple(nz.shape) != (B, self.noise_steps, self.C, self.V):
+                    raise ValueError(f"noise must be [B,{self.noise_steps},{self.C},{self.V}]")
+            else:
+                nz = torch.empty(B, self.noise_steps, self.C, self.V, dtype=torch.float32)
+                for b in range(B):
+                    g = torch.Generator()
+                    sd = None if seeds is None else seeds[b]
+                    if sd is None:
+                        g.seed()
+                    else:
+                        g.manual_seed(int(sd))
+                    nz[b].exponential_(1.0, generator=g)
+            self.noise = nz.to(dev)
+        else:
+            self.noise = None
+
+        self.sample_params = dict(cfg_scale=float(cfg_scale), temperature=float(temperature), top_p=float(top_p),
+                                  top_k=int(top_k or 0))
+        self._engine = C.c_void_p()
+        self._build_engine()
+        self.prefilled = False
+
+    # ------------------------------------------------------------------ engine descriptor
+    def _embed_args(self) -> hb.EmbedArgs:
+        e = hb.EmbedArgs()
+        e.tokens, e.cur = hb.ptr(self.tokens), hb.ptr(self.cur)
+        e.B, e.T, e.C, e.V, e.D = self.B, self.T, self.C, self.V, self.D
+        e.emb, e.g, e.x = hb.ptr(self.w.dec_emb), hb.ptr(self.w.dec_layers[0]["g_sa"]), hb.ptr(self.x)
+        e.P, e.p_plane_stride, e.p_ktiles = hb.ptr(self.planes_x), self.planes_x[0].numel(), self.xkt
+        e.ssq_ld, e.ssq = self.rows_pad, hb.ptr(self.ssq)
+        return e
+
+    def _sample_args(self) -> hb.SampleArgs:
+        da = self.cfg.data
+        s = hb.SampleArgs()
+        s.logits, s.ld_logits, s.B, s.T, s.C, s.V = hb.ptr(self.logits), self.ld_logits, self.B, self.T, self.C, self.V
+        s.max_tokens = self.max_tokens
+        s.cfg_scale, s.temperature, s.top_p = (self.sample_params[k] for k in ("cfg_scale", "temperature", "top_p"))
+        s.top_k = self.sample_params["top_k"]
+        s.eos, s.pad, s.bos, s.max_delay = da.audio_eos_value, da.audio_pad_value, da.audio_bos_value, self.max_delay
+        s.ignore_eos, s.teacher = int(self.ignore_eos), int(self.teacher)
+        s.delay, s.noise, s.noise_steps = hb.ptr(self.delay), hb.ptr(self.noise), self.noise_steps
+        s.tokens, s.pred, s.cur, s.fsm = hb.ptr(self.tokens), hb.ptr(self.pred), hb.ptr(self.cur), hb.ptr(self.fsm)
+        s.embed = self._embed_args()
+        return s
+
+    def _build_engine(self):
+        d = self.cfg.model.decoder
+        w = self.w
+        n = d.n_layer
+        self._layers = (hb.DecLayer * n)()
+        for i, L in enumerate(w.dec_layers):
+            dl = self._layers[i]
+            for key, f in (("qkv", "qkv"), ("o", "o"), ("cq", "cq"), ("co", "co"), ("wi", "wi"), ("wo", "wo")):
+                setattr(dl, "w_" + f, hb.ptr(L[key].t))
+                setattr(dl, "kt_" + f, L[key].kt)
+                setattr(dl, "ns_" + f, L[key].ns)
+            dl.g_sa, dl.g_ca, dl.g_mlp = hb.ptr(L["g_sa"]), hb.ptr(L["g_ca"]), hb.ptr(L["g_mlp"])
+            dl.k_self, dl.v_self = hb.ptr(self.k_self[i]), hb.ptr(self.v_self[i])
+            dl.k_cross, dl.v_cross = hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i])
+        ed = hb.EngineDesc()
+        ed.n_layer, ed.D, ed.F = n, self.D, self.F
+        ed.q_heads, ed.kv_heads, ed.cq_heads = d.gqa_query_heads, d.kv_heads, d.cross_query_heads
+        ed.C, ed.V, ed.B, ed.T, ed.S = self.C, self.V, self.B, self.T, self.S
+        ed.kv_dtype, ed.rows_pad, ed.ld_logits = self.kv_code, self.rows_pad, self.ld_logits
+        ed.eps = float(self.cfg.model.normalization_layer_epsilon)
+        ed.layers = C.cast(self._layers, C.POINTER(hb.DecLayer))
+        ed.w_logits, ed.kt_logits, ed.ns_logits = hb.ptr(w.logits.t), w.logits.kt, w.logits.ns
+        ed.g_final = hb.ptr(w.dec_norm)
+        ed.x, ed.planes_x, ed.planes_a, ed.planes_h = hb.ptr(self.x), hb.ptr(self.planes_x), hb.ptr(self.planes_a), hb.ptr(self.planes_h)
+        ed.ssq, ed.qkv, ed.qc, ed.logits = hb.ptr(self.ssq), hb.ptr(self.qkv), hb.ptr(self.qc), hb.ptr(self.logits)
+        ed.cos_t, ed.sin_t, ed.text_len = hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(self.text_len)
+        ed.sample = self._sample_args()
+        self._desc = ed
+        hb.check(hb.lib().dia_engine_create(C.byref(ed), C.c_void_p(self.stream.cuda_stream), C.byref(self._engine)),
+                 "dia_engine_create")
+
+    def close(self):
+        if self._engine:
+            hb.lib().dia_engine_destroy(self._engine)
+            self._engine = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ prefill
+    def prefill(self, keep_encoder_out: bool = False):
+        """Encoder + cross-K/V precompute for every utterance, then the first input embedding.
+        Replaces model.py:382-397 (Encoder.forward layers.py:445-462; precompute_cross_attn_cache 632-669)."""
+        L = hb.lib()
+        cfg, w, dev = self.cfg, self.w, self.dev
+        e, d = cfg.model.encoder, cfg.model.decoder
+        st = C.c_void_p(self.stream.cuda_stream)
+        E, Fe = e.n_embd, e.n_hidden
+        eps = float(cfg.model.normalization_layer_epsilon)
+        self.enc_out = []
+        with torch.cuda.stream(self.stream):
+            for b in range(self.B):
+                Lb = self.lens[b]
+                if Lb == 0:
+                    self.enc_out.append(None)
+                    continue
+                Lp = _ceil(Lb, 16)
+                mt = Lp // 16
+                ids = torch.from_numpy(self.text_ids[b]).to(dev)
+                x = torch.zeros(Lp, E, dtype=torch.float32, device=dev)
+                ekt, akt, hkt = E // 32, e.n_head * HEAD_DIM // 32, Fe // 32
+                px = torch.zeros(3, mt, ekt, 64, 8, dtype=torch.bfloat16, device=dev)
+                pa = torch.zeros(3, mt, akt, 64, 8, dtype=torch.bfloat16, device=dev)
+                ph = torch.zeros(3, mt, hkt, 64, 8, dtype=torch.bfloat16, device=dev)
+                ssq = torch.zeros(E // 16, Lp, dtype=torch.float32, device=dev)
+                nq = 3 * e.n_head * HEAD_DIM
+                qkv = torch.zeros(Lp, nq, dtype=torch.float32, device=dev)
+                kc = torch.zeros(e.n_head, Lp, HEAD_DIM, dtype=torch.float32, device=dev)
+                vc = torch.zeros(e.n_head, Lp, HEAD_DIM, dtype=torch.float32, device=dev)
+                hb.check(L.dia_embed_text(hb.ptr(ids), Lb, hb.ptr(w.enc_emb), E, hb.ptr(w.enc_layers[0]["g_sa"]), hb.ptr(x),
+                                          hb.ptr(px), px[0].numel(), ekt, hb.ptr(ssq), Lp, st), "dia_embed_text")
+
+                def gemm(A, a_kt, W: TiledW, epi, *, ssq_in=None, out=None, ldo=0, gnext=None, P=None, p_kt=0,
+                         ssq_out=None, kv=None):
+                    g = hb.GemmArgs()
+                    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), a_kt, Lb
+                    g.W, g.KT, g.nstrips, g.epi = hb.ptr(W.t), W.kt, W.ns, epi
+                    if ssq_in is not None:
+                        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq_in), E // 16, 1.0 / E, eps
+                    g.ssq_ld = Lp
+                    g.out, g.ldo = hb.ptr(out), ldo
+                    g.gnext = hb.ptr(gnext)
+                    if P is not None:
+                        g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), p_kt
+                    g.ssq_out = hb.ptr(ssq_out)
+                    if kv is not None:
+                        g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = kv
+                        g.cos_t, g.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
+                    hb.check(L.dia_gemm(C.byref(g), st), "dia_gemm")
+
+                for i, EL in enumerate(w.enc_layers):
+                    gemm(px, ekt, EL["qkv"], hb.EPI_SCALE_STORE, ssq_in=ssq, out=qkv, ldo=nq)
+                    hb.check(L.dia_enc_kv_prep(hb.ptr(qkv), nq, e.n_head * HEAD_DIM, 2 * e.n_head * HEAD_DIM, e.n_head, Lb, Lp,
+                                               hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(kc), hb.ptr(vc), st), "dia_enc_kv_prep")
+                    a = hb.AttnArgs()
+                    a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_ENC, hb.KV_F32, e.n_head, 1, Lb, Lp
+                    a.q, a.ldq, a.q_off = hb.ptr(qkv), nq, 0
+                    a.kc, a.vc, a.enc_len = hb.ptr(kc), hb.ptr(vc), Lb
+                    a.cos_t, a.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
+                    a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(pa), pa[0].numel(), akt
+                    hb.check(L.dia_attn(C.byref(a), st), "dia_attn(enc)")
+                    gemm(pa, akt, EL["o"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=EL["g_mlp"], P=px, p_kt=ekt, ssq_out=ssq)
+                    gemm(px, ekt, EL["wi"], hb.EPI_SWIGLU_EMIT, ssq_in=ssq, P=ph, p_kt=hkt)
+                    gnext = w.enc_layers[i + 1]["g_sa"] if i + 1 < len(w.enc_layers) else w.enc_norm
+                    gemm(ph, hkt, EL["wo"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=gnext, P=px, p_kt=ekt, ssq_out=ssq)
+                # px now holds planes(x * encoder.norm.weight); ssq the row sums of squares of x
+                for i, DL in enumerate(w.dec_layers):
+                    gemm(px, ekt, DL["ckv"], hb.EPI_CROSSKV, ssq_in=ssq,
+                         kv=(hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i]), self.kv_code, d.cross_query_heads, self.S, b))
+                if keep_encoder_out:
+                    inv = torch.rsqrt(ssq[:, :Lb].sum(dim=0) / E + eps)
+                    self.enc_out.append((x[:Lb] * inv[:, None] * w.enc_norm[None, :]).clone())
+                else:
+                    self.enc_out.append(None)
+            ea = self._embed_args()
+            hb.check(L.dia_embed_tokens(C.byref(ea), st), "dia_embed_tokens")
+        self.prefilled = True
+
+    # ------------------------------------------------------------------ decode
+    def decode(self, n_steps: int, use_graph: bool = True):
+        if not self.prefilled:
+            raise hb.DiaHipError("decode() before prefill()")
+        hb.check(hb.lib().dia_engine_decode(self._engine, int(n_steps), int(bool(use_graph))), "dia_engine_decode")
+
+    def step_logits_only(self):
+        hb.check(hb.lib().dia_engine_step_logits_only(self._engine), "dia_engine_step_logits_only")
+
+    def sync(self):
+        self.stream.synchronize()
+
+    def steps_total(self) -> int:
+        return self.max_tokens - self.prefill_step
+
+    def run(self, use_graph: bool = True, poll: int = 128):
+        """Run until every utterance has finished (EOS countdown or max_tokens); the host looks at
+        the device-side `done` flags every `poll` steps only."""
+        remaining = self.steps_total()
+        while remaining > 0:
+            n = min(poll, remaining)
+            self.decode(n, use_graph)
+            remaining -= n
+            self.sync()
+            if bool((self.fsm[:, 3] != 0).all().item()):
+                break
+
+    def logits_host(self) -> np.ndarray:
+        """fp32 [B, 2, C, V] logits of the last executed step."""
+        self.sync()
+        lg = self.logits[: self.R, : self.C * self.V].reshape(self.B, 2, self.C, self.V)
+        return lg.cpu().numpy()
+
+    def results(self) -> List[UtteranceResult]:
+        self.sync()
+        tok = self.tokens.cpu().numpy()
+        prd = self.pred.cpu().numpy()
+        fsm = self.fsm.cpu().numpy()
+        cur = self.cur.cpu().numpy()
+        out = []
+        for b in range(self.B):
+            last = int(fsm[b, 4]) if fsm[b, 3] else int(cur[b]) - 1
+            out.append(UtteranceResult(tok[b], tok[b, self.prefill_step: last + 1].copy(), last, prd[b], self.lens[b]))
+        return out
+
+    # ------------------------------------------------------------------ accounting
+    def step_bytes(self, n_keys: Optional[int] = None) -> int:
+        """Algorithmic HBM bytes of one decode step at self-KV length `n_keys` (default: current)."""
+        d = self.cfg.model.decoder
+        kvb = 4 if self.kv_code == hb.KV_F32 else 2
+        if n_keys is None:
+            n_keys = int(self.cur.max().item())
+        kv_self = 2 * d.n_layer * 2 * d.kv_heads * HEAD_DIM * kvb * n_keys      # both rows, K and V
+        kv_cross = d.n_layer * 2 * d.cross_query_heads * HEAD_DIM * kvb          # cond row, per text byte
+        return self.w.decode_weight_bytes() + self.B * kv_self + kv_cross * sum(self.lens)

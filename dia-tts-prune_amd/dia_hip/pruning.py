@@ -1,0 +1,70 @@
+"""Structured pruning of a Dia checkpoint and detection of pruned structure for repacking.
+
+``structured_prune_state_dict`` restates what the reference's ``offline_prune.py`` does in
+``--prune-mode structured`` (offline_prune.py:82-156 -> dia/pruning_utils.py:64-151): for every
+DenseGeneral kernel, rank the slices along ``dim`` by their L_n norm and zero the
+``round(amount * n_slices)`` weakest (``torch.nn.utils.prune.ln_structured`` followed by
+``prune.remove``) — the result is a same-shape checkpoint with zero slices and no mask.
+
+``kept_slices`` recovers the structure from the zeros (the checkpoint carries no mask,
+pruning_utils.py:145), which is what the loader uses to build physically smaller tensors.
+"""
+
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from .config import DiaConfig
+from .weights import param_shapes
+
+
+def prunable_names(cfg: DiaConfig):
+    """DenseGeneral kernels = everything the reference's get_prunable_modules finds in DiaModel
+    (pruning_utils.py:13-40): projections, MLP matrices and the logits head; embeddings and RMSNorm
+    weights are not DenseGeneral/Linear/Conv1d and stay untouched."""
+    return [k for k in param_shapes(cfg) if not (k.endswith("norm.weight") or "embedding" in k)]
+
+
+def structured_prune_state_dict(cfg: DiaConfig, sd: Dict[str, torch.Tensor], amount: float, dim: int = 0,
+                                n: int = 2) -> Tuple["OrderedDict[str, torch.Tensor]", Dict[str, np.ndarray]]:
+    """Returns (pruned state_dict, {name: kept slice indices along `dim`})."""
+    if not (0.0 < amount < 1.0):
+        raise ValueError("--prune-amount must be between 0.0 and 1.0 (exclusive).")   # offline_prune.py:58-60
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict((k, v.clone()) for k, v in sd.items())
+    kept: Dict[str, np.ndarray] = {}
+    for name in prunable_names(cfg):
+        w = out[name].float()
+        if dim >= w.dim():                      # pruning_utils.py:84-87: module skipped
+            continue
+        size = w.shape[dim]
+        n_prune = int(round(amount * size))
+        n_keep = size - n_prune
+        other = [a for a in range(w.dim()) if a != dim]
+        norm = torch.norm(w, p=n, dim=other)
+        keep_idx = torch.topk(norm, k=n_keep, largest=True).indices
+        mask = torch.zeros(size, dtype=torch.bool)
+        mask[keep_idx] = True
+        shape = [1] * w.dim()
+        shape[dim] = size
+        out[name] = (w * mask.view(shape)).to(sd[name].dtype)
+        kept[name] = torch.nonzero(mask).flatten().numpy().astype(np.int32)
+    return out, kept
+
+
+def kept_slices(w: torch.Tensor, dim: int = 0) -> np.ndarray:
+    """Indices along `dim` whose slice is not identically zero."""
+    moved = w.movedim(dim, 0).reshape(w.shape[dim], -1)
+    return torch.nonzero((moved != 0).any(dim=1)).flatten().cpu().numpy().astype(np.int32)
+
+
+def sparsity(cfg: DiaConfig, sd: Dict[str, torch.Tensor]) -> float:
+    """Global zero fraction over the prunable kernels (pruning_utils.py:153-179)."""
+    tot = zero = 0
+    for k in prunable_names(cfg):
+        tot += sd[k].numel()
+        zero += int((sd[k] == 0).sum().item())
+    return zero / max(tot, 1)

@@ -1,0 +1,232 @@
+/* libdia_hip.so — C ABI of the MI355X-native Dia decode path.
+ *
+ * The reference (babybirdprd/dia-tts-prune) has no native code and no FFI seam: its hot path is
+ * PyTorch ops called from dia/layers.py and dia/model.py.  This header therefore DEFINES the
+ * boundary a maintainer would bind (ctypes stub in INTEGRATION.md); every entry point names the
+ * reference call site whose arithmetic it replaces.  All pointers are raw device pointers unless
+ * marked "host"; no torch types cross this boundary.  Every function returns 0 on success and a
+ * negative DIA_E_* code on failure; dia_last_error() gives the message (thread-local).
+ *
+ * One engine per device / stream; an engine is not re-entrant (the reference's Dia object is not
+ * either: SURVEY.md §8b "Threading").
+ */
+#ifndef DIA_HIP_H
+#define DIA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIA_ABI_VERSION 1
+
+#define DIA_OK 0
+#define DIA_E_ARG (-1)     /* bad argument / unsupported shape */
+#define DIA_E_HIP (-2)     /* HIP runtime error */
+#define DIA_E_STATE (-3)   /* call order violated */
+
+#define DIA_KV_F32 0       /* parity mode: K/V caches in float32 */
+#define DIA_KV_BF16 1      /* perf mode (reference GPU bf16 path, state.py:142-151) */
+
+/* GEMM epilogues */
+#define DIA_EPI_SCALE_STORE 0  /* out[m][n] = acc * inv_rms[m]                      (q/k/v, cross-q, logits) */
+#define DIA_EPI_RESID_EMIT 1   /* x[m][n] += acc; emit planes(x*g_next), strip ssq   (o_proj, wo)             */
+#define DIA_EPI_SWIGLU_EMIT 2  /* h = silu(gate*inv)* (up*inv); emit planes(h)       (wi_fused)               */
+#define DIA_EPI_CROSSKV 3      /* K = RoPE(acc*inv) , V = acc*inv -> cross caches    (precompute_cross_attn_cache) */
+
+/* attention modes */
+#define DIA_ATTN_SELF 0   /* decoder self-attention over the growing cache (layers.py:541-555) */
+#define DIA_ATTN_CROSS 1  /* decoder cross-attention over encoder K/V, cond rows (layers.py:560-574) */
+#define DIA_ATTN_ENC 2    /* encoder bidirectional self-attention over L packed tokens (layers.py:396-404) */
+
+const char* dia_last_error(void);
+int dia_abi_version(void);
+/* number of visible HIP devices, or a negative error */
+int dia_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel-level entry points (unit parity tests call these; the engine below chains them).
+ * `stream` is a hipStream_t passed as void*.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* out[M][N] = X[M][K] . W[K][N] with X given as three bf16 planes and W as bf16 tiles.
+ * Replaces DenseGeneral.forward = torch.tensordot (layers.py:55-66) and, through its epilogues, the
+ * surrounding RMSNorm scale (layers.py:541,560,579,714), residual adds (555,574,582), the SwiGLU
+ * gate (layers.py:95-101) and the cross K/V RoPE + cache write (layers.py:652-663). */
+typedef struct {
+  const void* A;            /* planes base, bf16 */
+  int64_t a_plane_stride;   /* elements between planes */
+  int32_t a_ktiles;         /* K/32 of the plane layout */
+  int32_t M;                /* valid rows */
+  const void* W;            /* weight tiles, bf16 [nstrips][KT][64][8] */
+  int32_t KT;               /* K/32 */
+  int32_t nstrips;          /* N/16 */
+  int32_t epi;              /* DIA_EPI_* */
+  int32_t nw;               /* waves per workgroup (4, 8 or 16); 0 = choose */
+  /* row scale = rsqrt(sum_i ssq_in[i][m] * inv_d + eps); ssq_in == NULL -> scale 1 */
+  const float* ssq_in;
+  int32_t ssq_in_n;
+  int32_t ssq_ld;           /* row stride of ssq arrays (padded row count) */
+  float inv_d;
+  float eps;
+  float* out;               /* SCALE_STORE: [M][ldo]; RESID_EMIT: x in/out [M][ldo] */
+  int32_t ldo;
+  int32_t _pad0;
+  const float* gnext;       /* RESID_EMIT: norm weight of the consumer (NULL -> 1) */
+  void* P;                  /* emitted planes (RESID_EMIT, SWIGLU_EMIT) */
+  int64_t p_plane_stride;
+  int32_t p_ktiles;
+  int32_t _pad1;
+  float* ssq_out;           /* RESID_EMIT: [nstrips][ssq_ld] */
+  /* CROSSKV */
+  void* kc;                 /* K cache of one layer, [kv_batch][heads][kv_cap][128] */
+  void* vc;
+  int32_t kv_dtype;
+  int32_t kv_heads;
+  int32_t kv_cap;
+  int32_t kv_batch_index;
+  const float* cos_t;       /* [npos][64] */
+  const float* sin_t;
+} dia_gemm_args;
+int dia_gemm(const dia_gemm_args* a, void* stream);
+
+/* Single-query attention (decode) and the encoder's bidirectional attention on the same kernel.
+ * Replaces RotaryEmbedding.forward (layers.py:135-173), KVCache.update (state.py:99-103),
+ * repeat_interleave (layers.py:319-320) and F.scaled_dot_product_attention (layers.py:329-337). */
+typedef struct {
+  int32_t mode;             /* DIA_ATTN_* */
+  int32_t kv_dtype;
+  int32_t n_kv_heads;       /* grid.x */
+  int32_t group;            /* q heads per kv head: 4 (self), 1 (cross, enc) */
+  int32_t n_rows;           /* SELF: R = 2B rows; CROSS: B utterances; ENC: L tokens */
+  int32_t kv_cap;           /* cache capacity per head (audio_length / text capacity) */
+  const float* q;           /* fp32 [rows][ldq]; q head h at column q_off + h*128 */
+  int32_t ldq;
+  int32_t q_off;
+  int32_t k_off;            /* SELF: new k of kv head h at k_off + h*128, new v at v_off + h*128 */
+  int32_t v_off;
+  void* kc;                 /* [kv rows][n_kv_heads][kv_cap][128] */
+  void* vc;
+  const int32_t* cur;       /* SELF/CROSS: per-utterance current step (device) */
+  const int32_t* len;       /* CROSS: per-utterance text length (device); ENC: unused */
+  int32_t enc_len;          /* ENC: L */
+  int32_t _pad0;
+  const float* cos_t;
+  const float* sin_t;
+  void* P;                  /* output planes [3][mtiles][p_ktiles][64][8] */
+  int64_t p_plane_stride;
+  int32_t p_ktiles;
+  int32_t _pad1;
+} dia_attn_args;
+int dia_attn(const dia_attn_args* a, void* stream);
+
+/* Encoder helper: RoPE(k) and v of all L tokens from the qkv rows into an fp32 [heads][cap][128]
+ * scratch "cache" (layers.py:274-279,306-307 for the encoder). */
+int dia_enc_kv_prep(const float* qkv, int ldq, int k_off, int v_off, int heads, int L, int cap,
+                    const float* cos_t, const float* sin_t, float* kc, float* vc, void* stream);
+
+/* x[m][:] = table[ids[m]][:] for the text encoder (layers.py:452), plus planes(x*g) and strip ssq. */
+int dia_embed_text(const int32_t* ids, int L, const float* table, int D, const float* g, float* x,
+                   void* P, int64_t p_plane_stride, int p_ktiles, float* ssq, int ssq_ld, void* stream);
+
+/* Decoder input embedding: x[2b..2b+1][:] = sum_c emb_c[tokens[b][cur[b]-1][c]] (layers.py:691-696). */
+typedef struct {
+  const int32_t* tokens;    /* [B][T][C] */
+  const int32_t* cur;       /* [B] */
+  int32_t B, T, C, V, D;
+  int32_t _pad0;
+  const float* emb;         /* [C][V][D] fp32 */
+  const float* g;           /* first pre_sa_norm weight */
+  float* x;                 /* [rows][D] */
+  void* P;
+  int64_t p_plane_stride;
+  int32_t p_ktiles;
+  int32_t ssq_ld;
+  float* ssq;               /* [D/16][ssq_ld] */
+} dia_embed_args;
+int dia_embed_tokens(const dia_embed_args* a, void* stream);
+
+/* CFG + constraints + temperature / top-k / top-p / multinomial + EOS/delay state machine + token
+ * write + next-step embedding.  Replaces Dia._decoder_step (model.py:447-488), _sample_next_token
+ * (model.py:32-82) and the loop body at model.py:771-807 (device-side, no host sync). */
+typedef struct {
+  const float* logits;      /* [rows][ld_logits], channel c at column c*V */
+  int32_t ld_logits;
+  int32_t B;
+  int32_t T;                /* token buffer rows = audio_length */
+  int32_t C;
+  int32_t V;
+  int32_t max_tokens;
+  float cfg_scale, temperature, top_p;
+  int32_t top_k;
+  int32_t eos, pad, bos;
+  int32_t max_delay;
+  int32_t ignore_eos;       /* perf runs: natural EOS does not start the countdown */
+  int32_t teacher;          /* parity runs: record samples in `pred`, leave `tokens` untouched */
+  const int32_t* delay;     /* [C] device */
+  const float* noise;       /* [B][noise_steps][C][V] Exp(1) variates; step index = cur-1 */
+  int32_t noise_steps;
+  int32_t _pad0;
+  int32_t* tokens;          /* [B][T][C] */
+  int32_t* pred;            /* [B][T][C] raw samples per step (row cur) */
+  int32_t* cur;             /* [B] in/out */
+  int32_t* fsm;             /* [B][4]: eos_detected, eos_countdown, bos_countdown, done */
+  dia_embed_args embed;     /* next-step embedding; embed.tokens/cur are taken from above */
+} dia_sample_args;
+int dia_sample(const dia_sample_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Engine: owns nothing but the launch sequence.  All memory is allocated by the caller.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void *w_qkv, *w_o, *w_cq, *w_co, *w_wi, *w_wo;   /* weight tiles */
+  const float *g_sa, *g_ca, *g_mlp;                      /* RMSNorm weights [D] */
+  void *k_self, *v_self;                                 /* [R][kv_heads][T][128] */
+  void *k_cross, *v_cross;                               /* [B][cq_heads][S][128] */
+  int32_t kt_qkv, ns_qkv, kt_o, ns_o, kt_cq, ns_cq, kt_co, ns_co, kt_wi, ns_wi, kt_wo, ns_wo;
+} dia_dec_layer;
+
+typedef struct {
+  int32_t n_layer, D, F, q_heads, kv_heads, cq_heads, C, V;
+  int32_t B;                /* utterances; rows R = 2B */
+  int32_t T;                /* audio_length (self cache capacity, token buffer rows) */
+  int32_t S;                /* text capacity of the cross caches */
+  int32_t kv_dtype;
+  int32_t rows_pad;         /* 16 * ceil(R/16) */
+  int32_t ld_logits;        /* 16 * ceil(C*V/16) */
+  float eps;
+  int32_t _pad0;
+  const dia_dec_layer* layers;   /* host array [n_layer] */
+  const void* w_logits;
+  int32_t kt_logits, ns_logits;
+  const float* g_final;
+  /* scratch (device) */
+  float* x;                 /* [rows_pad][D] */
+  void* planes_x;           /* [3][rows_pad/16][D/32][64][8] */
+  void* planes_a;           /* attention output planes, width q_heads*128 */
+  void* planes_h;           /* MLP hidden planes, width F */
+  float* ssq;               /* [D/16][rows_pad] */
+  float* qkv;               /* [rows_pad][(q_heads+2*kv_heads)*128] */
+  float* qc;                /* [rows_pad][cq_heads*128] */
+  float* logits;            /* [rows_pad][ld_logits] */
+  const float* cos_t;       /* [T+1][64] */
+  const float* sin_t;
+  const int32_t* text_len;  /* [B] */
+  dia_sample_args sample;   /* sampler + FSM + embedding parameters */
+} dia_engine_desc;
+
+typedef struct dia_engine dia_engine;
+int dia_engine_create(const dia_engine_desc* d, void* stream, dia_engine** out);
+int dia_engine_destroy(dia_engine* e);
+/* enqueue `n_steps` decode steps; use_graph != 0 replays a captured hipGraph of one step */
+int dia_engine_decode(dia_engine* e, int n_steps, int use_graph);
+/* enqueue ONE decode step stopping after the logits GEMM (no sampling); for per-kernel timing */
+int dia_engine_step_logits_only(dia_engine* e);
+/* number of kernel launches in one decode step */
+int dia_engine_launches_per_step(const dia_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIA_HIP_H */

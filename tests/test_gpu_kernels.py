@@ -1,0 +1,379 @@
+"""Kernel-level parity on a real MI355X, through the C ABI, against float64 torch-CPU restatements of
+each op (and the oracle's sampler).  Tolerances: 2e-5 relative to the output scale for the fp32
+paths; token ids / integer outputs bit-exact."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dia_hip import binding as hb
+from dia_hip import layout as lay
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    return torch.device("cuda:0")
+
+
+def bf16r(t):
+    return t.bfloat16().float()
+
+
+def run_gemm(X, Wt, kt, ns, epi, *, akt=None, ssq_in=None, inv_d=0.0, eps=0.0, out=None, ldo=0, gnext=None, P=None,
+             p_kt=0, ssq_out=None, ssq_ld=0, kv=None, cos=None, sin=None, nw=0):
+    L = hb.lib()
+    M = X.shape[0]
+    A = lay.pack_planes(X, ktiles=akt)
+    g = hb.GemmArgs()
+    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+    g.W, g.KT, g.nstrips, g.epi, g.nw = hb.ptr(Wt), kt, ns, epi, nw
+    if ssq_in is not None:
+        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq_in), ssq_in.shape[0], inv_d, eps
+    g.ssq_ld = ssq_ld
+    g.out, g.ldo, g.gnext = hb.ptr(out), ldo, hb.ptr(gnext)
+    if P is not None:
+        g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), p_kt
+    g.ssq_out = hb.ptr(ssq_out)
+    if kv is not None:
+        g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = kv
+        g.cos_t, g.sin_t = hb.ptr(cos), hb.ptr(sin)
+    hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
+    torch.cuda.synchronize()
+    return A
+
+
+def strip_ssq(x, mpad):
+    M, D = x.shape
+    s = torch.zeros(D // 16, mpad, dtype=torch.float32, device=x.device)
+    s[:, :M] = (x.double() ** 2).reshape(M, D // 16, 16).sum(-1).T.float()
+    return s
+
+
+@pytest.mark.parametrize("M,K,N,nw", [(2, 2048, 2048, 0), (2, 2048, 3072, 16), (16, 512, 1024, 8), (20, 96, 80, 0),
+                                      (75, 256, 300, 4), (130, 1024, 64, 0), (2, 8192, 256, 16), (5, 2048, 9252, 4)])
+def test_gemm_scale_store(M, K, N, nw):
+    d = dev()
+    torch.manual_seed(M * 7 + K)
+    x = torch.randn(M, K, device=d) * 2.0
+    gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
+    W = bf16r(torch.randn(K, N, device=d) * 0.05)
+    Wt, kt, ns = lay.tile_weight(W)
+    mpad = (M + 15) // 16 * 16
+    has_norm = K % 16 == 0
+    ssq = strip_ssq(x, mpad) if has_norm else None
+    out = torch.full((M, ns * 16), float("nan"), device=d)
+    run_gemm(x * gw, Wt, kt, ns, hb.EPI_SCALE_STORE, ssq_in=ssq, inv_d=1.0 / K, eps=1e-5, out=out, ldo=ns * 16,
+             ssq_ld=mpad, nw=nw)
+    xd = x.double()
+    inv = torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5) if has_norm else 1.0
+    ref = ((xd * gw.double()) @ W.double()) * inv
+    err = (out[:, :N].double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    if ns * 16 > N:
+        assert (out[:, N:] == 0).all()
+
+
+@pytest.mark.parametrize("M,K,D", [(2, 2048, 2048), (16, 8192, 512), (37, 256, 96)])
+def test_gemm_resid_emit(M, K, D):
+    d = dev()
+    torch.manual_seed(K + D)
+    a = torch.randn(M, K, device=d)
+    W = bf16r(torch.randn(K, D, device=d) * 0.03)
+    x0 = torch.randn(M, D, device=d)
+    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+    Wt, kt, ns = lay.tile_weight(W)
+    mpad = (M + 15) // 16 * 16
+    x = x0.clone()
+    P = torch.zeros(3, mpad // 16, (D + 31) // 32, 64, 8, dtype=torch.bfloat16, device=d)
+    ssq = torch.zeros(ns, mpad, device=d)
+    run_gemm(a, Wt, kt, ns, hb.EPI_RESID_EMIT, out=x, ldo=D, gnext=gn, P=P, p_kt=P.shape[2], ssq_out=ssq, ssq_ld=mpad)
+    ref = x0.double() + a.double() @ W.double()
+    assert (x.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert torch.equal(lay.unpack_planes(P, M, D), x * gn)            # planes carry x*g exactly (3x bf16 == fp32)
+    want = (x.double() ** 2).reshape(M, D // 16, 16).sum(-1).T
+    assert (ssq[:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
+
+
+@pytest.mark.parametrize("M,K,F", [(2, 2048, 8192), (16, 256, 512), (33, 512, 1024)])
+def test_gemm_swiglu_emit(M, K, F):
+    d = dev()
+    torch.manual_seed(F)
+    x = torch.randn(M, K, device=d)
+    gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
+    wi = bf16r(torch.randn(K, 2, F, device=d) * 0.05)
+    Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi))
+    mpad = (M + 15) // 16 * 16
+    P = torch.zeros(3, mpad // 16, F // 32, 64, 8, dtype=torch.bfloat16, device=d)
+    run_gemm(x * gw, Wt, kt, ns, hb.EPI_SWIGLU_EMIT, ssq_in=strip_ssq(x, mpad), inv_d=1.0 / K, eps=1e-5, P=P, p_kt=F // 32,
+             ssq_ld=mpad)
+    xd = x.double()
+    h = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
+    f = torch.einsum("mk,kgf->mgf", h, wi.double())
+    ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
+    got = lay.unpack_planes(P, M, F).double()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("kvd", ["f32", "bf16"])
+def test_gemm_crosskv(kvd):
+    d = dev()
+    torch.manual_seed(3)
+    Lq, E, H, cap = 37, 256, 4, 48
+    x = torch.randn(Lq, E, device=d)
+    gw = bf16r(1.0 + 0.1 * torch.randn(E, device=d))
+    wk = bf16r(torch.randn(E, H, 128, device=d) * 0.05)
+    wv = bf16r(torch.randn(E, H, 128, device=d) * 0.05)
+    perm = lay.rope_pair_perm(128).to(d)
+    Wt, kt, ns = lay.tile_weight(torch.cat([wk[:, :, perm].reshape(E, -1), wv.reshape(E, -1)], dim=1))
+    cos, sin = [t.to(d) for t in lay.rope_tables(64, 128, 1, 10000)]
+    kdt = torch.float32 if kvd == "f32" else torch.bfloat16
+    kc = torch.zeros(2, H, cap, 128, dtype=kdt, device=d)
+    vc = torch.zeros(2, H, cap, 128, dtype=kdt, device=d)
+    mpad = (Lq + 15) // 16 * 16
+    code = hb.KV_F32 if kvd == "f32" else hb.KV_BF16
+    run_gemm(x * gw, Wt, kt, ns, hb.EPI_CROSSKV, ssq_in=strip_ssq(x, mpad), inv_d=1.0 / E, eps=1e-5, ssq_ld=mpad,
+             kv=(hb.ptr(kc), hb.ptr(vc), code, H, cap, 1), cos=cos, sin=sin)
+    xd = x.double()
+    h = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
+    k = torch.einsum("me,ehd->mhd", h, wk.double())
+    v = torch.einsum("me,ehd->mhd", h, wv.double())
+    c, s = cos[:Lq].double()[:, None, :], sin[:Lq].double()[:, None, :]
+    kr = torch.cat([k[..., :64] * c - k[..., 64:] * s, k[..., :64] * s + k[..., 64:] * c], dim=-1)
+    tol = 2e-5 if kvd == "f32" else 1e-2
+    assert (kc[1, :, :Lq].double().transpose(0, 1) - kr).abs().max().item() <= tol * kr.abs().max().item()
+    assert (vc[1, :, :Lq].double().transpose(0, 1) - v).abs().max().item() <= tol * v.abs().max().item()
+    assert (kc[0] == 0).all() and (kc[1, :, Lq:] == 0).all()
+
+
+def attn_ref(q, K, V):
+    """q [G,128] f64, K/V [t,128] f64"""
+    s = (q @ K.T) / math.sqrt(128.0)
+    p = torch.softmax(s, dim=-1)
+    return p @ V
+
+
+@pytest.mark.parametrize("kvd", ["f32", "bf16"])
+@pytest.mark.parametrize("B,cur", [(1, 1), (1, 37), (2, 300), (1, 1025)])
+def test_attn_self(kvd, B, cur):
+    d = dev()
+    torch.manual_seed(cur)
+    R, QH, KVH, T = 2 * B, 16, 4, 1280
+    nq = (QH + 2 * KVH) * 128
+    qkv = torch.randn(R, nq, device=d)
+    kdt = torch.float32 if kvd == "f32" else torch.bfloat16
+    kc = (torch.randn(R, KVH, T, 128, device=d)).to(kdt)
+    vc = (torch.randn(R, KVH, T, 128, device=d)).to(kdt)
+    kc0, vc0 = kc.clone(), vc.clone()
+    cos, sin = [t.to(d) for t in lay.rope_tables(T + 1, 128, 1, 10000)]
+    curs = torch.full((B,), cur, dtype=torch.int32, device=d)
+    mt = (R + 15) // 16
+    P = torch.zeros(3, mt, QH * 128 // 32, 64, 8, dtype=torch.bfloat16, device=d)
+    a = hb.AttnArgs()
+    a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_SELF, (0 if kvd == "f32" else 1), KVH, 4, R, T
+    a.q, a.ldq, a.q_off, a.k_off, a.v_off = hb.ptr(qkv), nq, 0, QH * 128, (QH + KVH) * 128
+    a.kc, a.vc, a.cur = hb.ptr(kc), hb.ptr(vc), hb.ptr(curs)
+    a.cos_t, a.sin_t = hb.ptr(cos), hb.ptr(sin)
+    a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(P), P[0].numel(), P.shape[2]
+    hb.check(hb.lib().dia_attn(C.byref(a), None), "dia_attn")
+    torch.cuda.synchronize()
+    out = lay.unpack_planes(P, R, QH * 128).double().reshape(R, QH, 128)
+
+    def rope(x, pos):
+        c, s = cos[pos].double(), sin[pos].double()
+        return torch.cat([x[..., :64] * c - x[..., 64:] * s, x[..., :64] * s + x[..., 64:] * c], dim=-1)
+
+    q = rope(qkv[:, : QH * 128].double().reshape(R, QH, 128), cur)
+    knew = rope(qkv[:, QH * 128: (QH + KVH) * 128].double().reshape(R, KVH, 128), cur)
+    vnew = qkv[:, (QH + KVH) * 128:].double().reshape(R, KVH, 128)
+    if kvd == "bf16":
+        knew, vnew = knew.float().bfloat16().double(), vnew.float().bfloat16().double()
+    slot = cur - 1
+    # cache append (state.py:99-103): slot written, everything else untouched
+    assert (kc[:, :, slot].double() - knew).abs().max().item() <= (1e-6 if kvd == "f32" else 0.0) + 1e-6
+    assert (vc[:, :, slot].double() - vnew).abs().max().item() <= 1e-6
+    keep = torch.ones(T, dtype=torch.bool, device=d); keep[slot] = False
+    assert torch.equal(kc[:, :, keep], kc0[:, :, keep]) and torch.equal(vc[:, :, keep], vc0[:, :, keep])
+    worst = 0.0
+    for r in range(R):
+        for h in range(KVH):
+            K = kc[r, h, :cur].double(); V = vc[r, h, :cur].double()
+            ref = attn_ref(q[r, 4 * h: 4 * h + 4], K, V)
+            worst = max(worst, (out[r, 4 * h: 4 * h + 4] - ref).abs().max().item())
+    assert worst <= 2e-5, worst
+
+
+@pytest.mark.parametrize("kvd", ["f32", "bf16"])
+def test_attn_cross_and_uncond_zero(kvd):
+    d = dev()
+    torch.manual_seed(11)
+    B, H, S = 3, 16, 208
+    lens = [75, 208, 0]
+    R = 2 * B
+    qc = torch.randn(R, H * 128, device=d)
+    kdt = torch.float32 if kvd == "f32" else torch.bfloat16
+    kc = torch.randn(B, H, S, 128, device=d).to(kdt)
+    vc = torch.randn(B, H, S, 128, device=d).to(kdt)
+    cos, sin = [t.to(d) for t in lay.rope_tables(512, 128, 1, 10000)]
+    cur = torch.tensor([5, 17, 9], dtype=torch.int32, device=d)
+    ln = torch.tensor(lens, dtype=torch.int32, device=d)
+    P = torch.full((3, 1, H * 128 // 32, 64, 8), 7.0, dtype=torch.bfloat16, device=d)
+    a = hb.AttnArgs()
+    a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_CROSS, (0 if kvd == "f32" else 1), H, 1, B, S
+    a.q, a.ldq = hb.ptr(qc), H * 128
+    a.kc, a.vc, a.cur, a.len = hb.ptr(kc), hb.ptr(vc), hb.ptr(cur), hb.ptr(ln)
+    a.cos_t, a.sin_t = hb.ptr(cos), hb.ptr(sin)
+    a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(P), P[0].numel(), P.shape[2]
+    hb.check(hb.lib().dia_attn(C.byref(a), None), "dia_attn")
+    torch.cuda.synchronize()
+    out = lay.unpack_planes(P, R, H * 128).double().reshape(R, H, 128)
+    for b in range(B):
+        assert (out[2 * b] == 0).all()                      # uncond row: fully masked -> exactly 0
+        c, s = cos[int(cur[b])].double(), sin[int(cur[b])].double()
+        q = qc[2 * b + 1].double().reshape(H, 128)
+        q = torch.cat([q[:, :64] * c - q[:, 64:] * s, q[:, :64] * s + q[:, 64:] * c], dim=-1)
+        if lens[b] == 0:
+            assert (out[2 * b + 1] == 0).all()
+            continue
+        for h in range(H):
+            ref = attn_ref(q[h: h + 1], kc[b, h, : lens[b]].double(), vc[b, h, : lens[b]].double())
+            assert (out[2 * b + 1, h] - ref[0]).abs().max().item() <= 2e-5
+
+
+def test_attn_encoder_mode_and_kv_prep():
+    d = dev()
+    torch.manual_seed(5)
+    Lq, H = 45, 4
+    nq = 3 * H * 128
+    qkv = torch.randn(Lq, nq, device=d)
+    cos, sin = [t.to(d) for t in lay.rope_tables(64, 128, 1, 10000)]
+    cap = 48
+    kc = torch.zeros(H, cap, 128, device=d); vc = torch.zeros(H, cap, 128, device=d)
+    Lb = hb.lib()
+    hb.check(Lb.dia_enc_kv_prep(hb.ptr(qkv), nq, H * 128, 2 * H * 128, H, Lq, cap, hb.ptr(cos), hb.ptr(sin), hb.ptr(kc), hb.ptr(vc), None), "prep")
+    P = torch.zeros(3, 3, H * 128 // 32, 64, 8, dtype=torch.bfloat16, device=d)
+    a = hb.AttnArgs()
+    a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_ENC, 0, H, 1, Lq, cap
+    a.q, a.ldq, a.enc_len = hb.ptr(qkv), nq, Lq
+    a.kc, a.vc = hb.ptr(kc), hb.ptr(vc)
+    a.cos_t, a.sin_t = hb.ptr(cos), hb.ptr(sin)
+    a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(P), P[0].numel(), P.shape[2]
+    hb.check(Lb.dia_attn(C.byref(a), None), "dia_attn")
+    torch.cuda.synchronize()
+    out = lay.unpack_planes(P, Lq, H * 128).double().reshape(Lq, H, 128)
+    c, s = cos[:Lq].double()[:, None], sin[:Lq].double()[:, None]
+
+    def rope(x):
+        return torch.cat([x[..., :64] * c - x[..., 64:] * s, x[..., :64] * s + x[..., 64:] * c], dim=-1)
+
+    q = rope(qkv[:, : H * 128].double().reshape(Lq, H, 128))
+    k = rope(qkv[:, H * 128: 2 * H * 128].double().reshape(Lq, H, 128))
+    v = qkv[:, 2 * H * 128:].double().reshape(Lq, H, 128)
+    assert (kc[:, :Lq].double().transpose(0, 1) - k).abs().max().item() <= 1e-6
+    for h in range(H):
+        ref = attn_ref(q[:, h], k[:, h], v[:, h])
+        assert (out[:, h] - ref).abs().max().item() <= 2e-5
+
+
+def _sampler_session(B, T, C_, V, D, logits_rows, noise, *, temperature, top_p, top_k, cfg_scale=0.0, cur=1,
+                     teacher=0, ignore_eos=0, max_tokens=None, tokens=None, fsm=None, delay=None):
+    d = dev()
+    ld = (C_ * V + 15) // 16 * 16
+    lg = torch.zeros((2 * B + 15) // 16 * 16, ld, device=d)
+    lg[: 2 * B, : C_ * V] = logits_rows.reshape(2 * B, C_ * V)
+    tok = torch.full((B, T, C_), -1, dtype=torch.int32, device=d) if tokens is None else tokens.clone()
+    pred = torch.full((B, T, C_), -1, dtype=torch.int32, device=d)
+    curs = torch.full((B,), cur, dtype=torch.int32, device=d)
+    if fsm is None:
+        fsm = torch.zeros(B, 8, dtype=torch.int32, device=d); fsm[:, 1] = -1; fsm[:, 2] = 0
+    emb = bf16r(torch.randn(C_, V, D, device=d) * 0.1)
+    gw = bf16r(1 + 0.1 * torch.randn(D, device=d))
+    x = torch.zeros(16, D, device=d)
+    P = torch.zeros(3, 1, D // 32, 64, 8, dtype=torch.bfloat16, device=d)
+    ssq = torch.zeros(D // 16, 16, device=d)
+    dl = torch.tensor(delay or [0, 8, 9, 10, 11, 12, 13, 14, 15][:C_], dtype=torch.int32, device=d)
+    s = hb.SampleArgs()
+    s.logits, s.ld_logits, s.B, s.T, s.C, s.V = hb.ptr(lg), ld, B, T, C_, V
+    s.max_tokens = T if max_tokens is None else max_tokens
+    s.cfg_scale, s.temperature, s.top_p, s.top_k = cfg_scale, temperature, top_p, top_k
+    s.eos, s.pad, s.bos, s.max_delay, s.ignore_eos, s.teacher = 1024, 1025, 1026, 15, ignore_eos, teacher
+    s.delay, s.noise, s.noise_steps = hb.ptr(dl), hb.ptr(noise), (0 if noise is None else noise.shape[1])
+    s.tokens, s.pred, s.cur, s.fsm = hb.ptr(tok), hb.ptr(pred), hb.ptr(curs), hb.ptr(fsm)
+    e = s.embed
+    e.D, e.emb, e.g, e.x = D, hb.ptr(emb), hb.ptr(gw), hb.ptr(x)
+    e.P, e.p_plane_stride, e.p_ktiles, e.ssq_ld, e.ssq = hb.ptr(P), P[0].numel(), D // 32, 16, hb.ptr(ssq)
+    keep = (lg, tok, pred, curs, fsm, emb, gw, x, P, ssq, dl, noise)
+    return s, keep
+
+
+def test_sampler_matches_reference_cases(golden):
+    """the reference's _sample_next_token outputs (tests/golden/ref_sampler.npz) on the device sampler"""
+    g = golden("ref_sampler.npz")
+    d = dev()
+    for i in range(int(g["n"])):
+        T_, tp, tk = g[f"params_{i}"]
+        lgc = torch.from_numpy(g[f"logits_{i}"]).to(d)
+        lgc = torch.where(torch.isinf(lgc), torch.zeros_like(lgc), lgc)       # masked entries are re-masked by the kernel
+        rows = torch.stack([lgc, lgc])                                         # uncond == cond, cfg_scale 0 -> guided == cond
+        steps = 40
+        nz = torch.ones(1, steps, 9, 1028, device=d)
+        nz[0, 0] = torch.from_numpy(g[f"noise_{i}"]).to(d)
+        s, keep = _sampler_session(1, 64, 9, 1028, 64, rows, nz, temperature=float(T_), top_p=float(tp),
+                                   top_k=(0 if tk < 0 else int(tk)), ignore_eos=1, max_tokens=41)
+        hb.check(hb.lib().dia_sample(C.byref(s), None), "dia_sample")
+        torch.cuda.synchronize()
+        pred = keep[2][0, 1].cpu().numpy()
+        assert np.array_equal(pred, g[f"out_{i}"]), (i, pred, g[f"out_{i}"])
+
+
+def test_sampler_fsm_and_embedding():
+    """EOS countdown / masked write / next-step embedding against a direct restatement of
+    model.py:771-807 + layers.py:691-696."""
+    d = dev()
+    torch.manual_seed(0)
+    B, T, C_, V, D = 2, 64, 9, 1028, 96
+    # utterance 0: natural EOS on channel 0 at step cur=20; utterance 1: inside the BOS window (cur=3)
+    rows = torch.randn(2 * B, C_, V, device=d)
+    rows[1, 0, 1024] = 50.0; rows[0, 0, 1024] = 50.0
+    tok = torch.full((B, T, C_), -1, dtype=torch.int32, device=d)
+    tok[1, 3, :] = torch.tensor([-1, 1026, 1026, 1026, 1026, 1026, 1026, 1026, 1026], dtype=torch.int32)
+    fsm = torch.zeros(B, 8, dtype=torch.int32, device=d); fsm[:, 1] = -1
+    fsm[0, 2] = 0; fsm[1, 2] = 13
+    s, keep = _sampler_session(B, T, C_, V, D, rows, None, temperature=0.0, top_p=0.95, top_k=35, cfg_scale=3.0, cur=20,
+                               tokens=tok, fsm=fsm)
+    keep[3][1] = 3
+    hb.check(hb.lib().dia_sample(C.byref(s), None), "dia_sample")
+    torch.cuda.synchronize()
+    lg, tok2, pred, curs, fsm2, emb, gw, x, P, ssq = keep[:10]
+    guided = rows[1::2] + 3.0 * (rows[1::2] - rows[0::2])
+    guided[:, :, 1025] = -math.inf; guided[:, :, 1026] = -math.inf; guided[:, 1:, 1024] = -math.inf
+    am = guided.argmax(-1).int()
+    assert torch.equal(pred[0, 20], am[0]) and torch.equal(pred[1, 3], am[1])
+    assert int(am[0, 0]) == 1024
+    # utt 0: eos detected, countdown 15 -> step_after_eos 0: channel 0 (delay 0) forced EOS, others keep samples
+    assert fsm2[0, :4].tolist() == [1, 14, 0, 0] and int(curs[0]) == 21
+    assert torch.equal(tok2[0, 20], am[0])
+    # utt 1: bos window: only the -1 entry is written
+    want = tok[1, 3].clone(); want[0] = am[1, 0]
+    assert torch.equal(tok2[1, 3], want) and fsm2[1, :4].tolist() == [0, -1, 12, 0] and int(curs[1]) == 4
+    # next-step embedding of the written rows
+    for b, row in ((0, tok2[0, 20]), (1, tok2[1, 3])):
+        e = emb[0, int(row[0])].clone()
+        for c in range(1, C_):
+            e = e + emb[c, int(row[c])]
+        assert torch.equal(x[2 * b], e) and torch.equal(x[2 * b + 1], e)
+        assert torch.equal(lay.unpack_planes(P, 4, D)[2 * b], e * gw)
+        assert (ssq[:, 2 * b].double() - (e.double() ** 2).reshape(-1, 16).sum(-1)).abs().max() < 1e-5
+
+
+def test_error_paths_on_device():
+    L = hb.lib()
+    d = dev()
+    g = hb.GemmArgs()
+    A = torch.zeros(3, 1, 2, 64, 8, dtype=torch.bfloat16, device=d)
+    Wt = torch.zeros(1, 4, 64, 8, dtype=torch.bfloat16, device=d)
+    g.A, g.a_plane_stride, g.a_ktiles, g.M, g.W, g.KT, g.nstrips = hb.ptr(A), A[0].numel(), 2, 2, hb.ptr(Wt), 4, 1
+    assert L.dia_gemm(C.byref(g), None) == -1 and b"exceeds" in L.dia_last_error()

@@ -1,0 +1,223 @@
+"""End-to-end parity of the HIP decode path against the CPU oracle and the reference's golden vectors.
+
+Tolerances (BASELINE.json north_star): logits within 1e-3 max-abs of the fp32 CPU path on identical
+seed/text, token ids bit-exact.  fp32-K/V mode is the parity configuration; bf16-K/V mode (the perf
+configuration = the reference's GPU bf16 cache) is checked against a stated looser bound.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dia_hip import config as C
+from dia_hip.engine import DecodeSession, DeviceWeights
+from dia_hip.model import Dia
+from dia_hip.tokens import codes_for_codec, effective_text, encode_text
+from dia_hip.weights import synthetic_state_dict
+from oracle import dia_oracle as O
+
+LOGIT_TOL = 1e-3          # north-star tolerance
+TEXTS = [
+    "[S1] Dia is an open weights text to dialogue model. [S2] You get full control over scripts and voices.",
+    "[S1] Hello there. [S2] Hi!",
+    "[S1] The quick brown fox jumps over the lazy dog, twice. [S2] Really? [S1] Yes.",
+]
+
+
+@pytest.fixture(scope="module")
+def mid():
+    cfg = C.mid_config()
+    sd = synthetic_state_dict(cfg, seed=1234, std=0.02)
+    w = DeviceWeights(cfg, sd, torch.device("cuda:0"))
+    return cfg, sd, w
+
+
+def oracle_run(cfg, sd, text, seed, max_tokens, **kw):
+    dm = O.Dims.of(cfg)
+    nz = O.exp_noise(seed, max_tokens - 1, dm.C, dm.tgt_vocab)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    return O.generate(sd, cfg, text, max_tokens=max_tokens, seed=None, noise=nz, mirror=False, **kw), nz
+
+
+def teacher_forced(w, cfg, texts, oracle_tokens, noises, max_tokens, kv="f32"):
+    ids = [encode_text(effective_text(t), cfg) for t in texts]
+    s = DecodeSession(w, ids, kv_dtype=kv, max_tokens=max_tokens, noise=torch.stack(noises), teacher_tokens=oracle_tokens)
+    s.prefill()
+    logits, n = [], max_tokens - 1
+    for _ in range(n):
+        s.decode(1, use_graph=False)
+        logits.append(s.logits_host())
+    res = s.results()
+    s.close()
+    return logits, res
+
+
+def test_teacher_forced_logits_and_tokens_mid(mid, golden):
+    cfg, sd, w = mid
+    g = golden("ref_mid.npz")
+    mt = int(g["max_tokens"])
+    r, nz = oracle_run(cfg, sd, TEXTS[0], 42, mt)
+    assert np.array_equal(r.tokens, g["tokens"])                       # oracle == reference (pinned)
+    logits, res = teacher_forced(w, cfg, [TEXTS[0]], [r.tokens], [nz], mt)
+    worst = 0.0
+    for i in range(len(r.logits)):
+        worst = max(worst, float(np.abs(logits[i][0] - r.logits[i]).max()))
+    print(f"mid teacher-forced: {len(r.logits)} steps, logits max-abs err {worst:.3e}")
+    assert worst <= LOGIT_TOL
+    # golden logits straight from the reference
+    for j, st in enumerate(g["logit_steps"]):
+        assert np.abs(logits[int(st)][0] - g["logits"][j]).max() <= LOGIT_TOL
+    # every per-step sample equals the oracle's sample (token ids bit-exact)
+    for i, p in enumerate(r.preds):
+        assert np.array_equal(res[0].preds[1 + i], p), i
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_free_running_tokens_mid(mid, golden, use_graph):
+    cfg, sd, w = mid
+    g = golden("ref_mid.npz")
+    mt = int(g["max_tokens"])
+    ids = [encode_text(effective_text(TEXTS[0]), cfg)]
+    s = DecodeSession(w, ids, kv_dtype="f32", max_tokens=mt, seeds=[42])
+    s.prefill()
+    s.run(use_graph=use_graph, poll=16)
+    res = s.results()[0]
+    s.close()
+    assert np.array_equal(res.tokens, g["tokens"])                     # the reference's token buffer, bit-exact
+    assert np.array_equal(res.codes, g["codes"])
+    assert np.array_equal(codes_for_codec(res.codes, cfg), g["codec_input"])
+    assert res.codes.shape[0] == mt - 2                                # App. B4: max_tokens=48 -> 47 steps, 46 rows
+
+
+def test_batched_equals_single(mid):
+    """B=3 mixed-length utterances in one loop == three independent oracle runs."""
+    cfg, sd, w = mid
+    mt = 40
+    seeds = [42, 7, 123]
+    runs = [oracle_run(cfg, sd, t, sd_, mt) for t, sd_ in zip(TEXTS, seeds)]
+    logits, res = teacher_forced(w, cfg, TEXTS, [r.tokens for r, _ in runs], [nz for _, nz in runs], mt)
+    worst = 0.0
+    for b, (r, _) in enumerate(runs):
+        for i in range(len(r.logits)):
+            worst = max(worst, float(np.abs(logits[i][b] - r.logits[i]).max()))
+        for i, p in enumerate(r.preds):
+            assert np.array_equal(res[b].preds[1 + i], p), (b, i)
+    print(f"batched teacher-forced logits max-abs err {worst:.3e}")
+    assert worst <= LOGIT_TOL
+    # free running, graph mode
+    ids = [encode_text(effective_text(t), cfg) for t in TEXTS]
+    s = DecodeSession(w, ids, kv_dtype="f32", max_tokens=mt, seeds=seeds)
+    s.prefill(); s.run(use_graph=True, poll=8)
+    out = s.results(); s.close()
+    for b, (r, _) in enumerate(runs):
+        assert np.array_equal(out[b].tokens, r.tokens), b
+        assert out[b].last_step == r.last_step
+
+
+def test_encoder_and_cross_kv_mid(mid, golden):
+    cfg, sd, w = mid
+    g = golden("ref_mid.npz")
+    ids = [encode_text(effective_text(TEXTS[0]), cfg)]
+    assert np.array_equal(ids[0], g["text_ids"][: int(g["L"])])
+    s = DecodeSession(w, ids, kv_dtype="f32", max_tokens=8, temperature=0.0)
+    s.prefill(keep_encoder_out=True); s.sync()
+    L = int(g["L"])
+    assert np.abs(s.enc_out[0].cpu().numpy() - g["enc_out_cond"]).max() <= 1e-4
+    for li, kk, vv in ((0, "cross_k_first", "cross_v_first"), (-1, "cross_k_last", "cross_v_last")):
+        assert np.abs(s.k_cross[li][0, :, :L].cpu().numpy() - g[kk]).max() <= 1e-4
+        assert np.abs(s.v_cross[li][0, :, :L].cpu().numpy() - g[vv]).max() <= 1e-4
+    s.close()
+
+
+def test_bf16_kv_mode_mid(mid):
+    """perf configuration: bf16 K/V caches.  Rounding K/V to 8 significand bits moves logits by
+    ~1e-2 at most on this model; tokens under teacher forcing still agree on almost every step."""
+    cfg, sd, w = mid
+    mt = 40
+    r, nz = oracle_run(cfg, sd, TEXTS[0], 42, mt)
+    logits, res = teacher_forced(w, cfg, [TEXTS[0]], [r.tokens], [nz], mt, kv="bf16")
+    worst = max(float(np.abs(logits[i][0] - r.logits[i]).max()) for i in range(len(r.logits)))
+    agree = np.mean([np.array_equal(res[0].preds[1 + i], p) for i, p in enumerate(r.preds)])
+    print(f"bf16-KV: logits max-abs err {worst:.3e}, per-step sample agreement {agree:.3f}")
+    assert worst <= 5e-2 and agree >= 0.8
+
+
+def test_termination_properties(mid):
+    """size-independent properties of the loop: forced EOS near max_tokens,
+    channel c receives EOS `delay[c]` steps after channel 0 and PAD afterwards, channel 8 never does."""
+    cfg, sd, w = mid
+    mt = 64
+    ids = [encode_text(effective_text(TEXTS[1]), cfg)]
+    s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=mt, seeds=[3], ignore_eos=True)
+    s.prefill(); s.run(use_graph=True, poll=32)
+    r = s.results()[0]; s.close()
+    assert r.last_step == mt - 2 and r.codes.shape[0] == mt - 2
+    tok = r.tokens
+    assert (tok[0] == 1026).all() and (tok[mt:] == -1).all() and (tok[mt - 1] != -1).all()
+    t0 = mt - 16 + 1                      # forced countdown starts after step mt-16 -> EOS on ch0 at mt-15
+    assert tok[t0, 0] == 1024
+    d = cfg.data.delay_pattern
+    for c in range(1, 8):
+        assert tok[t0 + d[c], c] == 1024, c
+        assert (tok[t0 + d[c] + 1: mt - 1, c] == 1025).all()
+    assert (tok[:mt, 8] != 1024).all()
+    assert (tok[1:15, 0] == 1025).all()    # BOS window keeps PAD on channel 0 (App. B4)
+
+
+def test_dia_api_from_state_dict(mid, golden, tmp_path):
+    cfg, sd, w = mid
+    g = golden("ref_mid.npz")
+    dia = Dia.from_state_dict(cfg, sd, "float32", torch.device("cuda:0"))
+    codes = dia.generate_codes(TEXTS[0], max_tokens=int(g["max_tokens"]), seed=42)
+    assert np.array_equal(codes, g["codec_input"])
+    # generate(): no codec offline -> prints and returns None like the reference (model.py:841-845)
+    assert dia.generate(TEXTS[0], max_tokens=20, seed=42) is None
+    assert dia.last_codes is not None and dia.last_codes.shape[:2] == (1, 9)
+    with pytest.raises(ValueError):
+        dia.generate("x", audio_prompt=torch.zeros(3, 9))
+    # from_local round trip (pruned-checkpoint loader path, offline_prune.py:153-155)
+    torch.save(sd, tmp_path / "pytorch_model.bin")
+    cfg.save(tmp_path / "config.json")
+    d2 = Dia.from_local(str(tmp_path / "config.json"), str(tmp_path / "pytorch_model.bin"), "float32", load_dac=False)
+    assert np.array_equal(d2.generate_codes(TEXTS[0], max_tokens=int(g["max_tokens"]), seed=42), g["codec_input"])
+    d3 = Dia.from_pretrained(str(tmp_path), "bfloat16", load_dac=False)
+    assert d3.generate_codes(TEXTS[1], max_tokens=24, seed=1).shape[0] == 1
+    with pytest.raises(FileNotFoundError):
+        Dia.from_local(str(tmp_path / "nope.json"), str(tmp_path / "pytorch_model.bin"))
+    with pytest.raises(RuntimeError):
+        Dia.from_pretrained(str(tmp_path), load_dac=True)           # DAC cannot be loaded offline
+
+
+def test_full_size_first_steps_vs_oracle():
+    """Dia-1.6B shapes, synthetic weights: teacher-forced logits of the first steps against the lean
+    CPU oracle (a few seconds of CPU work), then a graph-replayed run checked through the loop's
+    size-independent properties."""
+    cfg = C.dia_1_6b_config()
+    dev = torch.device("cuda:0")
+    sd_gpu = synthetic_state_dict(cfg, seed=1234, std=0.02, device=dev)
+    w = DeviceWeights(cfg, sd_gpu, dev)
+    sd = {k: v.cpu() for k, v in sd_gpu.items()}
+    del sd_gpu
+    torch.cuda.empty_cache()
+    steps = 4
+    mt = steps + 1
+    r, nz = oracle_run(cfg, sd, TEXTS[0], 42, mt, max_steps=steps)
+    nzp = nz[: mt - 1]
+    logits, res = teacher_forced(w, cfg, [TEXTS[0]], [r.tokens], [nzp], mt)
+    worst = max(float(np.abs(logits[i][0] - r.logits[i]).max()) for i in range(len(r.logits)))
+    print(f"Dia-1.6B teacher-forced: {len(r.logits)} steps, logits max-abs err {worst:.3e}, |logit| max {np.abs(r.logits[0]).max():.2f}")
+    assert worst <= LOGIT_TOL
+    for i, p in enumerate(r.preds):
+        assert np.array_equal(res[0].preds[1 + i], p), i
+    # graph replay == eager, bitwise
+    ids = [encode_text(effective_text(TEXTS[0]), cfg)]
+    outs = []
+    for use_graph in (False, True):
+        s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=34, seeds=[42], ignore_eos=True)
+        s.prefill(); s.run(use_graph=use_graph)
+        outs.append((s.results()[0].tokens.copy(), s.logits_host().copy()))
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

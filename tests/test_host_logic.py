@@ -1,0 +1,145 @@
+"""Host-side logic of the product package (no GPU): token helpers against the reference's vectors,
+config round trip, layouts, synthetic weights."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dia_hip import config as C
+from dia_hip import layout as lay
+from dia_hip import tokens as T
+from dia_hip import weights as W
+
+
+def test_text_helpers_match_reference(golden):
+    g = golden("ref_textprep.npz")
+    cfg = C.tiny_config()
+    for i in range(int(g["n"])):
+        eff = T.effective_text(str(g[f"text_{i}"]))
+        assert eff == str(g[f"eff_{i}"])
+        ids = T.encode_text(eff, cfg)
+        assert np.array_equal(T.padded_text_ids(ids, cfg), g[f"ids_{i}"])
+    pre, step = T.delayed_prefill(cfg)
+    assert step == int(g["prefill_step"]) and np.array_equal(pre, g["prefill"])
+
+
+def test_effective_text_edges():
+    assert T.effective_text("") == ""
+    assert T.effective_text("  hello ") == "hello [S2]"
+    assert T.effective_text("[S1] a [S2]") == "[S1] a [S2] [S1]"
+    assert T.effective_text("[S1] a [S2] b [S1]") == "[S1] a [S2] b [S1] [S2]"
+    assert T.effective_text("x", "[S1] p") == "[S1] p x [S2]"
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_codec_input_matches_reference(golden, name):
+    g = golden(f"ref_{name}.npz")
+    cfg = C.tiny_config() if name == "tiny" else C.mid_config()
+    assert np.array_equal(T.codes_for_codec(g["codes"], cfg), g["codec_input"])
+    assert T.codes_for_codec(g["codes"][:0], cfg).shape == (1, 9, 0)
+    assert T.codes_for_codec(g["codes"][:10], cfg).shape == (1, 9, 0)     # shorter than max delay
+
+
+def test_prefill_with_prompt_rows():
+    cfg = C.tiny_config()
+    prompt = np.arange(5 * 9, dtype=np.int32).reshape(5, 9) % 1000
+    pre, step = T.delayed_prefill(cfg, prompt)
+    assert step == 6 and pre.shape == (21, 9)
+    d = cfg.data.delay_pattern
+    for c in range(9):
+        for t in range(21):
+            ts = t - d[c]
+            want = 1026 if ts < 0 else (1026 if ts == 0 else (prompt[ts - 1, c] if ts <= 5 else 1025))
+            assert pre[t, c] == want
+
+
+def test_config_roundtrip(tmp_path):
+    cfg = C.dia_1_6b_config()
+    assert W.param_count(cfg) == 1_611_196_416 or W.param_count(cfg) // 10**6 == 1611
+    p = tmp_path / "sub" / "cfg"
+    cfg.save(p)
+    assert (tmp_path / "sub" / "cfg.json").is_file()
+    back = C.DiaConfig.load(tmp_path / "sub" / "cfg.json")
+    assert back == cfg
+    assert C.DiaConfig.load(tmp_path / "nope.json") is None
+    d = C.config_to_json_dict(cfg)
+    d["data"]["text_length"] = 1000                      # rounded up to a multiple of 128
+    assert C.config_from_json_dict(d).data.text_length == 1024
+    with pytest.raises(Exception):
+        C.DataConfig(text_length=0, audio_length=128)
+    with pytest.raises(Exception):                       # frozen
+        cfg.data.channels = 3
+    # hub-mixin style wrapper {"config": {...}}
+    (tmp_path / "config.json").write_text(json.dumps({"config": C.config_to_json_dict(cfg)}))
+    assert W.read_hub_config(str(tmp_path / "config.json")) == cfg
+
+
+def test_tile_and_plane_layouts():
+    torch.manual_seed(0)
+    w = torch.randn(70, 45).bfloat16().float()
+    t, kt, ns = lay.tile_weight(w)
+    assert (kt, ns) == (3, 3) and t.shape == (3, 3, 64, 8)
+    assert torch.equal(lay.untile_weight(t, 70, 45), w)
+    # lane l of tile (strip, kt) holds W[32kt + 8(l>>4) + j][16 strip + (l&15)]
+    for (s, k, l, j) in [(0, 0, 0, 0), (2, 1, 37, 5), (1, 2, 63, 7)]:
+        kk, nn = 32 * k + 8 * (l >> 4) + j, 16 * s + (l & 15)
+        want = w[kk, nn] if kk < 70 and nn < 45 else 0.0
+        assert float(t[s, k, l, j]) == float(want)
+    x = torch.randn(19, 70) * 3
+    p = lay.pack_planes(x)
+    assert p.shape == (3, 2, 3, 64, 8)
+    assert torch.equal(lay.unpack_planes(p, 19, 70), x)           # hi+mid+lo is exact
+    for (m, k) in [(0, 0), (17, 69), (5, 33)]:
+        mt, ktile, lane, j = m >> 4, k >> 5, (m & 15) + 16 * ((k & 31) >> 3), k & 7
+        assert float(p[0, mt, ktile, lane, j]) == float(x[m, k].bfloat16())
+
+
+def test_interleave_and_rope_perm():
+    wi = torch.arange(4 * 2 * 16, dtype=torch.float32).reshape(4, 2, 16)
+    out = lay.interleave_gate_up(wi)
+    assert out.shape == (4, 32)
+    assert torch.equal(out[:, 0:8], wi[:, 0, 0:8]) and torch.equal(out[:, 8:16], wi[:, 1, 0:8])
+    assert torch.equal(out[:, 16:24], wi[:, 0, 8:16]) and torch.equal(out[:, 24:32], wi[:, 1, 8:16])
+    perm = lay.rope_pair_perm(128)
+    assert perm[:4].tolist() == [0, 64, 1, 65] and sorted(perm.tolist()) == list(range(128))
+
+
+def test_synthetic_weights_deterministic_and_bf16():
+    cfg = C.tiny_config()
+    a = W.synthetic_state_dict(cfg, seed=1234, std=0.08)
+    b = W.synthetic_state_dict(cfg, seed=1234, std=0.08)
+    c = W.synthetic_state_dict(cfg, seed=1235, std=0.08)
+    assert list(a.keys()) == list(W.param_shapes(cfg).keys())
+    for k in a:
+        assert torch.equal(a[k], b[k])
+        assert torch.equal(a[k], a[k].bfloat16().float())          # bf16-representable
+    k = "decoder.layers.0.mlp.wo.weight"
+    assert not torch.equal(a[k], c[k])
+    assert abs(a[k].std().item() - 0.08) < 0.01
+    # chunking does not change the stream
+    t1 = W.synthetic_tensor("x", (1000,), 7, 0.02, chunk=1 << 24)
+    t2 = W.synthetic_tensor("x", (1000,), 7, 0.02, chunk=64)
+    assert torch.equal(t1, t2)
+    assert torch.all(a["decoder.norm.weight"] == 1)
+
+
+def test_checkpoint_io(tmp_path):
+    cfg = C.tiny_config()
+    sd = W.synthetic_state_dict(cfg, seed=1, std=0.05)
+    torch.save(dict(sd, **{"x.lora_A.weight": torch.zeros(1)}), tmp_path / "pytorch_model.bin")
+    cfg.save(tmp_path / "config.json")
+    cpath, wpath = W.find_checkpoint_in_dir(str(tmp_path))
+    back = W.load_state_dict_file(wpath)
+    assert "x.lora_A.weight" not in back                           # model.py:172
+    assert W.check_state_dict(cfg, back) == ([], [])
+    from safetensors.torch import save_file
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / "model.safetensors"))
+    assert W.find_checkpoint_in_dir(str(tmp_path))[1].endswith("model.safetensors")
+    bad = dict(sd)
+    bad["decoder.norm.weight"] = torch.ones(3)
+    with pytest.raises(RuntimeError):
+        W.check_state_dict(cfg, bad)
+    with pytest.raises(FileNotFoundError):
+        W.find_checkpoint_in_dir(str(tmp_path / "missing"))
