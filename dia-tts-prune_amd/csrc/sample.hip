@@ -337,7 +337,7 @@ extern "C" int dia_embed_text(const int32_t* ids, int L, const float* table, int
 }
 
 int dia_sample_init() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
   if (e != hipSuccess) return dia_fail_hip(e, "hipFuncSetAttribute(k_sample)");
   return DIA_OK;
 }

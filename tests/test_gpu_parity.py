@@ -35,10 +35,20 @@ def mid():
     return cfg, sd, w
 
 
+def cpu_threads():
+    """the GPU box gives a 1-GPU job a 16-core share of a much larger host: never size OpenMP pools
+    from os.cpu_count() there"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
 def oracle_run(cfg, sd, text, seed, max_tokens, **kw):
     dm = O.Dims.of(cfg)
     nz = O.exp_noise(seed, max_tokens - 1, dm.C, dm.tgt_vocab)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(cpu_threads())
     return O.generate(sd, cfg, text, max_tokens=max_tokens, seed=None, noise=nz, mirror=False, **kw), nz
 
 
