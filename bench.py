@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X decode path: audio-codec frames/s/GPU for Dia-1.6B (+ RTF).
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+A "step" is one decode step of the whole batch (one frame per utterance = 9 codebook tokens).
+Workload at N=1: BASELINE.json configs[1] — Dia-1.6B shapes, bf16 weights + bf16 K/V, batch 1,
+1024 decode steps, synthetic seeded weights (no checkpoint exists offline), README prompt.
+Everything is resident in HBM before the timed region; the loop replays one hipGraph per step and
+never syncs with the host inside the region.  Prints ONE JSON line (rank 0).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dia-tts-prune_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PROMPT = "[S1] Dia is an open weights text to dialogue model. [S2] You get full control over scripts and voices."
+SENT = "[S1] Dia is an open weights text to dialogue model. [S2] You get full control over scripts and voices. "
+MIXED_L = [32, 64, 96, 128, 192, 256, 384, 512]
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+FRAME_RATE = 44100.0 / 512.0   # 86.13 frames per second of audio
+LAUNCH_NAMES = ["qkv", "attn_self", "o", "cq", "attn_cross", "co", "wi", "wo"]
+
+
+def cpu_threads() -> int:
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))     # a 1-GPU job owns a 16-core share of the host
+
+
+def texts_for(batch: int):
+    if batch == 1:
+        return [PROMPT]
+    out = []
+    for i in range(batch):
+        L = MIXED_L[i % len(MIXED_L)]
+        out.append((SENT * 8)[: L - 5])          # effective_text appends " [Sx]" (5 bytes)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU")
+    ap.add_argument("--kv", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dia_hip import config as C
+    from dia_hip.engine import DecodeSession, DeviceWeights
+    from dia_hip.tokens import effective_text, encode_text
+    from dia_hip.weights import synthetic_state_dict
+    from dia_hip.dist import broadcast_weights
+
+    cfg = C.dia_1_6b_config()
+    K, Wm = args.steps, args.warmup
+    max_tokens = 1 + Wm + K + args.profile_steps + 1
+    if max_tokens > cfg.data.audio_length:
+        raise SystemExit(f"warmup+steps must stay below audio_length={cfg.data.audio_length}")
+
+    # ---- weights: rank 0 builds + repacks, the other ranks receive the repacked tensors over RCCL
+    t0 = time.time()
+    sd_gpu = synthetic_state_dict(cfg, seed=1234, std=0.02, device=dev) if rank == 0 else None
+    if rank == 0:
+        w = DeviceWeights(cfg, sd_gpu, dev)
+    else:
+        w = DeviceWeights.empty_like_config(cfg, dev)
+    bcast_s = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        tb = time.time()
+        broadcast_weights(w, src=0)
+        torch.cuda.synchronize()
+        bcast_s = time.time() - tb
+    load_s = time.time() - t0
+
+    texts = texts_for(args.batch)
+    ids = [encode_text(effective_text(t), cfg) for t in texts]
+    seeds = [42 + 1000 * rank + i for i in range(args.batch)]
+    sess = DecodeSession(w, ids, kv_dtype=args.kv, max_tokens=max_tokens, seeds=seeds, ignore_eos=True)
+    tp = time.time()
+    sess.prefill()
+    sess.sync()
+    prefill_s = time.time() - tp
+
+    use_graph = not args.no_graph
+    sess.decode(Wm, use_graph)
+    sess.sync()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t1 = time.perf_counter()
+    ev0.record(sess.stream)
+    sess.decode(K, use_graph)
+    ev1.record(sess.stream)
+    sess.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t1
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    cur_after = int(sess.cur.min().item())
+    assert cur_after == 1 + Wm + K, (cur_after, Wm, K)        # every timed step really executed
+
+    # ---- per-launch HIP-event timing of eager steps (KV length ~ Wm+K), on the engine's stream
+    prof = np.stack([sess.profile_step() for _ in range(args.profile_steps)]) if args.profile_steps > 0 else None
+    nl = cfg.model.decoder.n_layer
+    roof = None
+    breakdown = None
+    if prof is not None:
+        per = prof[:, : nl * 8].reshape(-1, nl, 8)                 # [rep, layer, kind]
+        kind_ms = per.mean(axis=(0, 1))
+        breakdown = {LAUNCH_NAMES[i]: round(float(kind_ms[i]) * 1e3, 2) for i in range(8)}
+        breakdown["logits"] = round(float(prof[:, nl * 8].mean()) * 1e3, 2)
+        breakdown["sample_fsm_embed"] = round(float(prof[:, nl * 8 + 1].mean()) * 1e3, 2)
+        breakdown["unit"] = "us per launch (eager, event-bracketed)"
+        wi_ms = float(kind_ms[6])
+        wi_bytes = w.dec_layers[0]["wi"].nbytes                  # algorithmic bytes of the dominant kernel
+        roof = {"bound": "hbm", "kernel": "k_gemm<MT=1,NW=4,KPW=16> (wi_fused GEMV, SwiGLU epilogue)",
+                "achieved": round(wi_bytes / (wi_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(wi_bytes / (wi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_per_launch": wi_bytes, "us_per_launch": round(wi_ms * 1e3, 2), "traffic": None}
+        tr = os.path.join(ROOT, "profiles", "traffic_wi.json")
+        if os.path.isfile(tr):
+            try:
+                roof["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+
+    frames = world * args.batch * K
+    value = frames / elapsed
+    ms_per_step = elapsed / K * 1e3
+    # whole-step algorithmic traffic, averaged over the timed region's KV lengths
+    n_mid = Wm + (K + 1) / 2.0
+    step_bytes = sess.step_bytes(int(round(n_mid)))
+    step_gbs = step_bytes / (dev_ms / K * 1e-3) / 1e9
+
+    out = {
+        "metric": "audio-codec frames/sec (Dia-1.6B decode, whole job)", "value": round(value, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Dia-1.6B bf16 weights, {args.kv} K/V, batch {args.batch} per GPU, {K} decode steps, "
+                               f"text bytes {sess.lens}, cfg 3.0 / T 1.3 / top-p 0.95 / top-k 35, hipGraph={use_graph}",
+                   "batch_per_gpu": args.batch, "parallelism": f"dp{world}" if world > 1 else "single"},
+        "frames_per_s_per_gpu": round(value / world, 2), "rtf_per_gpu": round(value / world / args.batch / FRAME_RATE, 3),
+        "rtf_aggregate": round(value / FRAME_RATE, 2),
+        "prefill_s": round(prefill_s, 4), "weights_load_s": round(load_s, 2), "weights_bcast_s": round(bcast_s, 3),
+        "device_ms_per_step": round(dev_ms / K, 4),
+        "step_roofline": {"bytes_per_step": int(step_bytes), "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
+        "launch_breakdown": breakdown,
+    }
+    if roof is not None:
+        out["roofline"] = roof
+
+    # ---- CPU baseline: the oracle in mirror mode (= the reference's op sequence incl. its dead
+    #      cross-K/V work), fp32, same weights/prompt/seed, bounded sample, rank 0 at N=1 only
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        from oracle import dia_oracle as O
+        nthr = cpu_threads()
+        torch.set_num_threads(nthr)
+        sd_cpu = {k: v.cpu() for k, v in sd_gpu.items()}
+        del sd_gpu
+        tc = time.time()
+        r = O.generate(sd_cpu, cfg, PROMPT, max_tokens=cfg.data.audio_length, seed=42, mirror=True,
+                       keep_logits=False, max_steps=args.cpu_steps)
+        total = time.time() - tc
+        med = float(np.median(r.step_ms))
+        out["cpu_baseline"] = {
+            "value": round(1e3 / med, 3), "unit": "frames/s", "cores": nthr, "kind": "port",
+            "sample": f"oracle mirror mode (reference op sequence incl. dead cross-K/V re-projection), fp32, batch 1, "
+                      f"prefill {r.prep_s:.1f}s + {len(r.step_ms)} decode steps, median {med:.0f} ms/step, {total:.1f}s total",
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    sess.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,12 @@ struct dia_engine {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   int launches = 0;
+  std::vector<hipEvent_t> prof;   // when non-empty: one event recorded after every launch (profile step)
 };
+
+static inline void mark(dia_engine* e, int i) {
+  if (!e->prof.empty() && i + 1 < (int)e->prof.size()) (void)hipEventRecord(e->prof[i + 1], e->stream);
+}
 
 static int kernels_init_once() {
   static int rc = -100;
@@ -47,14 +52,14 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.W = L.w_qkv; g.KT = L.kt_qkv; g.nstrips = L.ns_qkv; g.epi = DIA_EPI_SCALE_STORE;
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
     g.out = d.qkv; g.ldo = nqkv;
-    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     dia_attn_args a = {};
     a.mode = DIA_ATTN_SELF; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.kv_heads; a.group = d.q_heads / d.kv_heads;
     a.n_rows = R; a.kv_cap = d.T; a.q = d.qkv; a.ldq = nqkv; a.q_off = 0; a.k_off = d.q_heads * 128;
     a.v_off = (d.q_heads + d.kv_heads) * 128; a.kc = L.k_self; a.vc = L.v_self; a.cur = d.sample.cur;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
-    if ((rc = dia_attn(&a, st))) return rc; ++n;
+    if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
 
     // o_proj + residual; emits the pre-CA-normed planes (layers.py:341-343, 555, 560)
     g = {};
@@ -62,7 +67,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.W = L.w_o; g.KT = L.kt_o; g.nstrips = L.ns_o; g.epi = DIA_EPI_RESID_EMIT;
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_ca;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
-    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // cross-attention query (layers.py:273, 278)
     g = {};
@@ -70,21 +75,21 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.W = L.w_cq; g.KT = L.kt_cq; g.nstrips = L.ns_cq; g.epi = DIA_EPI_SCALE_STORE;
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
     g.out = d.qc; g.ldo = d.cq_heads * 128;
-    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     a = {};
     a.mode = DIA_ATTN_CROSS; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.cq_heads; a.group = 1;
     a.n_rows = d.B; a.kv_cap = d.S; a.q = d.qc; a.ldq = d.cq_heads * 128; a.q_off = 0;
     a.kc = L.k_cross; a.vc = L.v_cross; a.cur = d.sample.cur; a.len = d.text_len;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
-    if ((rc = dia_attn(&a, st))) return rc; ++n;
+    if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
 
     g = {};
     g.A = d.planes_a; g.a_plane_stride = as; g.a_ktiles = akt; g.M = R;
     g.W = L.w_co; g.KT = L.kt_co; g.nstrips = L.ns_co; g.epi = DIA_EPI_RESID_EMIT;
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_mlp;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
-    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // SwiGLU MLP (layers.py:95-104)
     g = {};
@@ -92,7 +97,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.W = L.w_wi; g.KT = L.kt_wi; g.nstrips = L.ns_wi; g.epi = DIA_EPI_SWIGLU_EMIT;
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
     g.P = d.planes_h; g.p_plane_stride = hs; g.p_ktiles = hkt;
-    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     g = {};
     g.A = d.planes_h; g.a_plane_stride = hs; g.a_ktiles = hkt; g.M = R;
@@ -100,7 +105,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D;
     g.gnext = (l + 1 < d.n_layer) ? e->layers[l + 1].g_sa : d.g_final;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
-    if ((rc = dia_gemm(&g, st))) return rc; ++n;
+    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
   }
   // final norm + logits (layers.py:714-717)
   dia_gemm_args g = {};
@@ -108,9 +113,9 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   g.W = d.w_logits; g.KT = d.kt_logits; g.nstrips = d.ns_logits; g.epi = DIA_EPI_SCALE_STORE;
   g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
   g.out = d.logits; g.ldo = d.ld_logits;
-  if ((rc = dia_gemm(&g, st))) return rc; ++n;
+  if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
   if (with_sampler) {
-    if ((rc = dia_sample(&d.sample, st))) return rc; ++n;
+    if ((rc = dia_sample(&d.sample, st))) return rc; mark(e, n++);
   }
   e->launches = n;
   return DIA_OK;
@@ -174,6 +179,26 @@ extern "C" int dia_engine_decode(dia_engine* e, int n_steps, int use_graph) {
 extern "C" int dia_engine_step_logits_only(dia_engine* e) {
   if (!e) return dia_fail(DIA_E_ARG, "dia_engine_step_logits_only: null engine");
   return enqueue_step(e, false);
+}
+
+extern "C" int dia_engine_profile_step(dia_engine* e, float* ms, int cap) {
+  if (!e || !ms) return dia_fail(DIA_E_ARG, "dia_engine_profile_step: null argument");
+  const int n = e->d.n_layer * 8 + 2;
+  if (cap < n) return dia_fail(DIA_E_ARG, "dia_engine_profile_step: output array too small");
+  e->prof.resize(n + 1);
+  for (auto& ev : e->prof) {
+    hipError_t he = hipEventCreate(&ev);
+    if (he != hipSuccess) return dia_fail_hip(he, "hipEventCreate");
+  }
+  (void)hipEventRecord(e->prof[0], e->stream);
+  int rc = enqueue_step(e, true);
+  hipError_t he = hipStreamSynchronize(e->stream);
+  if (rc == DIA_OK && he != hipSuccess) rc = dia_fail_hip(he, "hipStreamSynchronize");
+  if (rc == DIA_OK)
+    for (int i = 0; i < n; ++i) (void)hipEventElapsedTime(&ms[i], e->prof[i], e->prof[i + 1]);
+  for (auto& ev : e->prof) (void)hipEventDestroy(ev);
+  e->prof.clear();
+  return rc;
 }
 
 extern "C" int dia_engine_launches_per_step(const dia_engine* e) {

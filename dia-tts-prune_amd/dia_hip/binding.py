@@ -22,7 +22,7 @@ ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
 EXPORTS = (
     "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_attn", "dia_enc_kv_prep",
     "dia_embed_text", "dia_embed_tokens", "dia_sample", "dia_engine_create", "dia_engine_destroy",
-    "dia_engine_decode", "dia_engine_step_logits_only", "dia_engine_launches_per_step",
+    "dia_engine_decode", "dia_engine_step_logits_only", "dia_engine_profile_step", "dia_engine_launches_per_step",
 )
 
 
@@ -116,6 +116,11 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` or "
             f"`make -C dia-tts-prune_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    # torch ships its own libamdhip64 / libhsa-runtime64; load it FIRST so that this library binds to
+    # the same HIP runtime instance as the tensors whose pointers it receives (two runtimes in one
+    # process do not share a device context)
+    import torch  # noqa: F401
+
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64.so not found
@@ -140,6 +145,7 @@ def lib() -> C.CDLL:
     L.dia_engine_decode.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.dia_engine_step_logits_only.argtypes = [C.c_void_p]
     L.dia_engine_launches_per_step.argtypes = [C.c_void_p]
+    L.dia_engine_profile_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     _lib = L
     return L
 

@@ -97,6 +97,13 @@ class DeviceWeights:
         cos, sin = lay.rope_tables(npos, HEAD_DIM, m.rope_min_timescale, m.rope_max_timescale)
         self.cos_t, self.sin_t = cos.to(device), sin.to(device)
 
+    @classmethod
+    def empty_like_config(cls, cfg: DiaConfig, device: torch.device) -> "DeviceWeights":
+        """Same tensors, zero-filled: the receive side of the multi-GPU weight broadcast."""
+        from .weights import param_shapes
+        sd = {k: torch.zeros(shp, dtype=torch.float32, device=device) for k, shp in param_shapes(cfg).items()}
+        return cls(cfg, sd, device)
+
     def decode_weight_bytes(self) -> int:
         """bf16 bytes one decode step streams (SURVEY.md §8d 'W'): every decoder matrix except the
         prefill-only cross K/V projections, plus the logits head."""
@@ -367,6 +374,13 @@ class DecodeSession:
 
     def step_logits_only(self):
         hb.check(hb.lib().dia_engine_step_logits_only(self._engine), "dia_engine_step_logits_only")
+
+    def profile_step(self) -> np.ndarray:
+        """per-launch milliseconds of one eager decode step (HIP events on the engine's stream)."""
+        n = hb.lib().dia_engine_launches_per_step(self._engine)
+        buf = (C.c_float * n)()
+        hb.check(hb.lib().dia_engine_profile_step(self._engine, buf, n), "dia_engine_profile_step")
+        return np.array(buf[:], dtype=np.float64)
 
     def sync(self):
         self.stream.synchronize()

@@ -223,6 +223,10 @@ int dia_engine_destroy(dia_engine* e);
 int dia_engine_decode(dia_engine* e, int n_steps, int use_graph);
 /* enqueue ONE decode step stopping after the logits GEMM (no sampling); for per-kernel timing */
 int dia_engine_step_logits_only(dia_engine* e);
+/* run ONE eager decode step with a HIP event recorded on the engine's stream after every launch and
+ * return the elapsed milliseconds of each launch (launch order: per layer qkv, attn_self, o, cq,
+ * attn_cross, co, wi, wo; then logits, sampler).  Synchronises the stream. */
+int dia_engine_profile_step(dia_engine* e, float* ms_per_launch, int cap);
 /* number of kernel launches in one decode step */
 int dia_engine_launches_per_step(const dia_engine* e);
 
