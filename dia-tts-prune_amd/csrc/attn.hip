@@ -21,6 +21,7 @@ namespace {
 constexpr int HD = 128;
 constexpr int NT = 512;            // threads per workgroup
 constexpr int NGRP = NT / 16;      // key groups
+constexpr int U = 4;               // keys per lane group per round (independent loads in flight)
 
 struct AttnK {
   int mode, n_kv_heads, n_rows, kv_cap;
@@ -77,7 +78,6 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
     const float c = p.cos_t[(long)pos * 64 + d], s = p.sin_t[(long)pos * 64 + d];
     const float k1 = KVElem<KVT>::round(x1 * c - x2 * s), k2 = KVElem<KVT>::round(x1 * s + x2 * c);
     const float v1 = KVElem<KVT>::round(vh[d]), v2 = KVElem<KVT>::round(vh[d + 64]);
-    knew[d] = k1; knew[d + 64] = k2; vnew[d] = v1; vnew[d + 64] = v2;
     KVElem<KVT>::store(Kc + (long)slot * HD + d, k1);
     KVElem<KVT>::store(Kc + (long)slot * HD + d + 64, k2);
     KVElem<KVT>::store(Vc + (long)slot * HD + d, v1);
@@ -93,24 +93,26 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) qreg[g][j] = q_s[g * HD + sub * 8 + j];
   const float scale = 0.08838834764831845f;   // 1/sqrt(128)
-  for (int key = grp; key < nkeys; key += NGRP) {
-    float kv[8];
-    if (key == slot) {
+  // U keys per lane group per round, all U loads issued before the first use.  The key written by
+  // this workgroup in the prologue is read back from memory like any other (the barrier above orders it).
+  for (int key0 = grp; key0 < nkeys; key0 += NGRP * U) {
+    float kv[U][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) kv[j] = knew[sub * 8 + j];
-    } else {
-      KVElem<KVT>::load8(Kc + (long)key * HD + sub * 8, kv);
-    }
+    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Kc + (long)min(key0 + u * NGRP, nkeys - 1) * HD + sub * 8, kv[u]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float s = 0.f;
+    for (int u = 0; u < U; ++u) {
+      const int key = key0 + u * NGRP;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += qreg[g][j] * kv[j];
-      s += __shfl_xor(s, 8, 64);
-      s += __shfl_xor(s, 4, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 1, 64);
-      if (sub == 0) sc[g * sc_ld + key] = s * scale;
+      for (int g = 0; g < G; ++g) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += qreg[g][j] * kv[u][j];
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if (sub == 0 && key < nkeys) sc[g * sc_ld + key] = s * scale;
+      }
     }
   }
   __syncthreads();
@@ -138,19 +140,19 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
-  for (int key = grp; key < nkeys; key += NGRP) {
-    float vv[8];
-    if (key == slot) {
+  for (int key0 = grp; key0 < nkeys; key0 += NGRP * U) {
+    float vv[U][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) vv[j] = vnew[sub * 8 + j];
-    } else {
-      KVElem<KVT>::load8(Vc + (long)key * HD + sub * 8, vv);
-    }
+    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Vc + (long)min(key0 + u * NGRP, nkeys - 1) * HD + sub * 8, vv[u]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float pk = sc[g * sc_ld + key];
+    for (int u = 0; u < U; ++u) {
+      const int key = key0 + u * NGRP;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[g][j] += pk * vv[j];
+      for (int g = 0; g < G; ++g) {
+        const float pk = key < nkeys ? sc[g * sc_ld + key] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] += pk * vv[u][j];
+      }
     }
   }
 #pragma unroll

@@ -20,12 +20,19 @@ typedef uint16_t bf16_raw;
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
 
-// v == hi + mid + lo, each bf16 (round-to-nearest-even at every stage)
+// v == hi + mid + lo exactly, each bf16 (round-to-nearest-even at every stage; both residuals are
+// exact in fp32).  Contraction is off here and in mul_rn(): fusing a preceding multiply into the
+// subtraction would split the unrounded product instead of the fp32 value v.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+#pragma clang fp contract(off)
   hi = (__bf16)v;
-  float r = v - (float)hi;
+  const float r = v - (float)hi;
   mid = (__bf16)r;
-  float r2 = r - (float)mid;
+  const float r2 = r - (float)mid;
   lo = (__bf16)r2;
 }
 

@@ -50,34 +50,91 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
   const int kt0 = w * kpw;
 
   f32x4 acc[MT];
-  int mtile[MT];   // rows >= M are computed on whatever the (clamped) tile holds and never stored
+  long aoff[MT];   // per m-tile element offset of this lane's A fragment at k-tile 0
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mtile[i] = min(mt0 + i, (p.M - 1) >> 4);
+    // rows >= M: the lane re-reads the last valid row of the (clamped) tile — same 16 B as its
+    // neighbour, so it costs no extra L2 traffic; its results are never stored
+    const int mtile = min(mt0 + i, (p.M - 1) >> 4);
+    const int rlast = min(15, p.M - 1 - mtile * 16);
+    const int alane = (lane & 48) | min(lane & 15, rlast);
+    aoff[i] = ((long)mtile * p.a_ktiles * 64 + alane) * 8;
   }
 
   const bf16x8* Wt = reinterpret_cast<const bf16x8*>(p.W) + ((long)strip * p.KT) * 64 + lane;
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
+  // epilogue geometry (threads 0 .. MT*32-1: one row, 8 consecutive columns each)
+  const int e_mt = tid >> 5, e_r = (tid >> 1) & 15, half = tid & 1;
+  const int m = (mt0 + e_mt) * 16 + e_r;
+  const int n0 = strip * 16 + half * 8;
+  const bool e_thread = tid < MT * 32;
+  const bool live = e_thread && m < p.M;
+  float xpre[8], gpre[8];
+
+  auto prefetch_epilogue = [&]() {
+    // everything the epilogue needs from memory is requested now, behind the weight loads, so that
+    // its latency overlaps theirs instead of adding a dependent round trip at the end
+    if (p.epi == DIA_EPI_RESID_EMIT && live) {
+      const float* o = p.out + (long)m * p.ldo + n0;
+      const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+      xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+      xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gpre[j] = p.gnext ? p.gnext[n0 + j] : 1.0f;
+    }
+    for (int t = tid; t < MT * 128; t += NW * 64) {       // 8 threads per row sum the strip partials
+      const int r = t >> 3, part = t & 7;
+      const int row = mt0 * 16 + r;
+      float sA = 0.f, sB = 0.f;
+      if (p.ssq_in != nullptr && row < p.M) {
+        int i = part;
+        for (; i + 8 < p.ssq_in_n; i += 16) {
+          sA += p.ssq_in[(long)i * p.ssq_ld + row];
+          sB += p.ssq_in[(long)(i + 8) * p.ssq_ld + row];
+        }
+        if (i < p.ssq_in_n) sA += p.ssq_in[(long)i * p.ssq_ld + row];
+      }
+      float sq = sA + sB;
+      sq += __shfl_xor(sq, 1, 64);
+      sq += __shfl_xor(sq, 2, 64);
+      sq += __shfl_xor(sq, 4, 64);
+      if (part == 0) inv_s[r] = (p.ssq_in != nullptr) ? rsqrtf(sq * p.inv_d + p.eps) : 1.0f;
+    }
+  };
+
   if constexpr (KPW > 0) {
     bf16x8 b[KPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) b[i] = __builtin_nontemporal_load(Wt + (long)(kt0 + i) * 64);
-    __builtin_amdgcn_sched_barrier(0);   // every HBM load of this wave is in flight before the L2-resident A loads
+    __builtin_amdgcn_sched_barrier(0);   // every HBM load of this wave is in flight before anything else
+    // k-tiles of A fetched up front (registers: 12*MT per k-tile; a 16-wave workgroup has 128 VGPRs)
+    constexpr int AP = (KPW >= 8) ? 1 : ((KPW * MT <= 4) ? KPW : ((4 / MT) > 0 ? (4 / MT) : 1));
+    bf16x8 a0[AP][MT][DIA_NPLANES];
+#pragma unroll
+    for (int i = 0; i < AP; ++i)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < DIA_NPLANES; ++pl)
+          a0[i][mt][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt0 + i) * 512);
+    prefetch_epilogue();
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const bf16x8* Af = reinterpret_cast<const bf16x8*>(p.A) + ((long)mtile[mt] * p.a_ktiles + (kt0 + i)) * 64 + lane;
 #pragma unroll
         for (int pl = 0; pl < DIA_NPLANES; ++pl) {
-          bf16x8 a = Af[(pl * p.a_plane_stride) >> 3];
+          bf16x8 a;
+          if (i < AP) a = a0[i < AP ? i : 0][mt][pl];
+          else a = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt0 + i) * 512);
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
         }
       }
     }
   } else {
+    prefetch_epilogue();
     const int kt1 = min(kt0 + kpw, p.KT);
     for (int kt = kt0; kt < kt1; kt += 4) {
       bf16x8 b[4];
@@ -88,10 +145,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
         if (kt + i < kt1) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            const bf16x8* Af = reinterpret_cast<const bf16x8*>(p.A) + ((long)mtile[mt] * p.a_ktiles + (kt + i)) * 64 + lane;
 #pragma unroll
             for (int pl = 0; pl < DIA_NPLANES; ++pl) {
-              bf16x8 a = Af[(pl * p.a_plane_stride) >> 3];
+              bf16x8 a = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt + i) * 512);
               acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
             }
           }
@@ -103,19 +159,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
   // ---- split-K partials -> LDS, fixed-order sum by wave 0..MT-1
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) red[(w * MT + mt) * 64 + lane] = acc[mt];
-
-  // row scales while the partials land (threads 0 .. MT*16*8-1: 8 threads per row)
-  for (int t = tid; t < MT * 128; t += NW * 64) {
-    const int r = t >> 3, part = t & 7;
-    const int row = mt0 * 16 + r;
-    float s = 0.f;
-    if (p.ssq_in != nullptr && row < p.M)
-      for (int i = part; i < p.ssq_in_n; i += 8) s += p.ssq_in[(long)i * p.ssq_ld + row];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (part == 0) inv_s[r] = (p.ssq_in != nullptr) ? rsqrtf(s * p.inv_d + p.eps) : 1.0f;
-  }
   __syncthreads();
   if (tid < MT * 64) {
     const int mt = tid >> 6;
@@ -132,13 +175,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
   __syncthreads();
 
   // ---- epilogue: MT*32 threads, each 8 consecutive columns of one row
-  if (tid >= MT * 32) return;
-  const int mt = tid >> 5, r = (tid >> 1) & 15, half = tid & 1;
-  const int m = (mt0 + mt) * 16 + r;
-  const float* trow = tile + (mt * 16 + r) * 17;
-  const float inv = inv_s[mt * 16 + r];
-  const int n0 = strip * 16 + half * 8;
-  const bool live = m < p.M;
+  if (!e_thread) return;
+  const float* trow = tile + (e_mt * 16 + e_r) * 17;
+  const float inv = inv_s[e_mt * 16 + e_r];
 
   if (p.epi == DIA_EPI_SCALE_STORE) {
     if (!live) return;
@@ -152,19 +191,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
     float ss = 0.f;
     if (live) {
       float* o = p.out + (long)m * p.ldo + n0;
-      float4 xa = *reinterpret_cast<float4*>(o), xb = *reinterpret_cast<float4*>(o + 4);
-      v[0] = xa.x + trow[half * 8 + 0]; v[1] = xa.y + trow[half * 8 + 1];
-      v[2] = xa.z + trow[half * 8 + 2]; v[3] = xa.w + trow[half * 8 + 3];
-      v[4] = xb.x + trow[half * 8 + 4]; v[5] = xb.y + trow[half * 8 + 5];
-      v[6] = xb.z + trow[half * 8 + 6]; v[7] = xb.w + trow[half * 8 + 7];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = xpre[j] + trow[half * 8 + j];
       *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
       *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
 #pragma unroll
       for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
-      if (p.gnext != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= p.gnext[n0 + j];
-      }
+      for (int j = 0; j < 8; ++j) v[j] = mul_rn(v[j], gpre[j]);
       emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, m, n0, v);
     }
     float other = __shfl_xor(ss, 1, 64);
@@ -212,10 +246,12 @@ template <int MT, int NW>
 int launch_kpw(const GemmK& k, int mgroups, hipStream_t st) {
   if (k.KT % NW == 0) {
     switch (k.KT / NW) {
+      case 1: return launch<MT, NW, 1>(k, mgroups, st);
       case 2: return launch<MT, NW, 2>(k, mgroups, st);
       case 4: return launch<MT, NW, 4>(k, mgroups, st);
       case 8: return launch<MT, NW, 8>(k, mgroups, st);
-      case 16: return launch<MT, NW, 16>(k, mgroups, st);
+      case 16: if constexpr (NW <= 8) return launch<MT, NW, 16>(k, mgroups, st); else break;
+      case 32: if constexpr (NW <= 8) return launch<MT, NW, 32>(k, mgroups, st); else break;
       default: break;
     }
   }
@@ -261,9 +297,11 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
 
   int nw = a->nw;
   if (nw == 0) {
-    // many strips -> few fat waves (deep load queues); few strips -> many waves per strip
-    if (a->nstrips >= 512 && a->KT % 4 == 0 && a->KT / 4 <= 16) nw = 4;
-    else if (a->KT % 16 == 0) nw = 16;
+    // many strips -> few fat waves (deep load queues); few strips -> many waves per strip.
+    // A 16-wave workgroup has 128 VGPRs per lane: it keeps at most 8 weight tiles (32 VGPRs) in flight
+    // per wave; longer K ranges go to 8-wave workgroups (256 VGPRs).
+    if (a->nstrips >= 512 && a->KT % 4 == 0 && a->KT / 4 <= 32) nw = 4;
+    else if (a->KT % 16 == 0 && a->KT / 16 <= 8) nw = 16;
     else if (a->KT % 8 == 0) nw = 8;
     else nw = 4;
   }

@@ -46,6 +46,21 @@ __device__ __forceinline__ void embed_rows(const EmbedK& e, int b, const int* to
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (e.C == 9) {
+      float4 ra[9], rb[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const float* r = e.emb + ((long)c * e.V + tok[c]) * e.D + d0;
+        ra[c] = *reinterpret_cast<const float4*>(r);
+        rb[c] = *reinterpret_cast<const float4*>(r + 4);
+      }
+      v[0] = ra[0].x; v[1] = ra[0].y; v[2] = ra[0].z; v[3] = ra[0].w; v[4] = rb[0].x; v[5] = rb[0].y; v[6] = rb[0].z; v[7] = rb[0].w;
+#pragma unroll
+      for (int c = 1; c < 9; ++c) {   // sequential sum in channel order (layers.py:696)
+        v[0] += ra[c].x; v[1] += ra[c].y; v[2] += ra[c].z; v[3] += ra[c].w;
+        v[4] += rb[c].x; v[5] += rb[c].y; v[6] += rb[c].z; v[7] += rb[c].w;
+      }
+    } else
     for (int c = 0; c < e.C; ++c) {
       const float* r = e.emb + ((long)c * e.V + tok[c]) * e.D + d0;
       const float4 a = *reinterpret_cast<const float4*>(r), bq = *reinterpret_cast<const float4*>(r + 4);
@@ -138,7 +153,13 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
     const int n = cur - 1;                                                          // executed steps so far
     const float* un = p.logits + (long)(2 * b) * p.ld_logits + c * p.V;
     const float* co = p.logits + (long)(2 * b + 1) * p.ld_logits + c * p.V;
-    float lg[NV];
+    float lg[NV], qn[NV];
+    const float* q = (p.temperature != 0.0f) ? p.noise + (((long)b * p.noise_steps + n) * p.C + c) * p.V : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {       // Exp(1) variates requested together with the logits
+      const int v = lane + 64 * i;
+      qn[i] = (q != nullptr && v < p.V) ? q[v] : 1.0f;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = lane + 64 * i;
@@ -176,6 +197,7 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
 #pragma unroll
           for (int i = 0; i < NV; ++i) cnt += __popcll(__ballot(key[i] >= cand));
           if (cnt >= k) pre = cand;
+          if (cnt == k) break;          // exactly the k largest already separated: same mask as the full search
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) if (key[i] < pre) lg[i] = -INFINITY;
@@ -244,13 +266,12 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) { e2[i] = expf(lg[i] - m2); z2 += e2[i]; }
       z2 = wave_sum(z2);
-      const float* q = p.noise + (((long)b * p.noise_steps + n) * p.C + c) * p.V;
       float bv = -1.f; int bi = 0x7fffffff;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int v = lane + 64 * i;
         if (v < p.V) {
-          const float sc = (e2[i] / z2) / q[v];
+          const float sc = (e2[i] / z2) / qn[i];
           if (sc > bv) { bv = sc; bi = v; }
         }
       }
@@ -260,47 +281,46 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
   }
   __syncthreads();
 
-  // ---- token state machine (one thread) --------------------------------------------------------
-  if (tid == 0) {
+  // ---- token state machine: wave 0, lane i = channel i (all global accesses issued in parallel) ----
+  if (c == 0) {
     int go = 0;
     if (!done) {
-      int eos_detected = fsm[0], eos_countdown = fsm[1], bos_countdown = fsm[2];
+      const bool ch = lane < p.C;
       int* prow = p.pred + ((long)b * p.T + cur) * p.C;
       int* trow = p.tokens + ((long)b * p.T + cur) * p.C;
-      int pr[MAXC];
-      for (int i = 0; i < p.C; ++i) { pr[i] = preds[i]; prow[i] = pr[i]; }
-      int finished = 0, last = cur;
-      if (p.teacher) {
-        for (int i = 0; i < p.C; ++i) tok_next[i] = trow[i];
-      } else {
-        if (!eos_detected && pr[0] == p.eos && !p.ignore_eos) { eos_detected = 1; eos_countdown = p.max_delay; }
+      int eos_detected = fsm[0], eos_countdown = fsm[1], bos_countdown = fsm[2];      // same address in every lane
+      const int old = ch ? trow[lane] : 0;
+      const int d = ch ? p.delay[lane] : 0;
+      int pr = ch ? preds[lane] : 0;
+      if (ch) prow[lane] = pr;
+      const int pr0 = __shfl(pr, 0, 64);
+      int finished = 0, last = cur, tk = old;
+      if (!p.teacher) {
+        if (!eos_detected && pr0 == p.eos && !p.ignore_eos) { eos_detected = 1; eos_countdown = p.max_delay; }
         if (eos_countdown > 0) {
           const int after = p.max_delay - eos_countdown;
-          for (int i = 0; i < p.C; ++i) {
-            const int d = p.delay[i];
-            if (after == d) pr[i] = p.eos;
-            else if (after > d && pr[i] != p.eos) pr[i] = p.pad;
-          }
+          if (after == d) pr = p.eos;
+          else if (after > d && pr != p.eos) pr = p.pad;
           eos_countdown -= 1;
         }
         bos_countdown = max(0, bos_countdown - 1);
-        for (int i = 0; i < p.C; ++i) {
-          int t = pr[i];
-          if (bos_countdown > 0) { const int old = trow[i]; if (old != -1) t = old; }
-          trow[i] = t;
-          tok_next[i] = t;
-        }
-        if (eos_countdown == 0) { finished = 1; last = cur - 1; }                   // model.py:795-797 (break)
+        tk = (bos_countdown > 0 && old != -1) ? old : pr;
+        if (ch) trow[lane] = tk;
+        if (eos_countdown == 0) { finished = 1; last = cur - 1; }                     // model.py:795-797 (break)
         else if (cur >= p.max_tokens - p.max_delay - 1 && !eos_detected) { eos_detected = 1; eos_countdown = p.max_delay; }
       }
+      if (ch) tok_next[lane] = tk;
       if (!finished) {
-        last = cur;                                                                  // dec_step += 1
-        if (cur + 1 > p.max_tokens - 1) finished = 1;                                // while dec_step < max_tokens-1
-        else { p.cur[b] = cur + 1; go = 1; }
+        last = cur;                                                                    // dec_step += 1
+        if (cur + 1 > p.max_tokens - 1) finished = 1;                                  // while dec_step < max_tokens-1
+        else go = 1;
       }
-      fsm[0] = eos_detected; fsm[1] = eos_countdown; fsm[2] = bos_countdown; fsm[3] = finished; fsm[4] = last;
+      if (lane == 0) {
+        if (go) p.cur[b] = cur + 1;
+        fsm[0] = eos_detected; fsm[1] = eos_countdown; fsm[2] = bos_countdown; fsm[3] = finished; fsm[4] = last;
+      }
     }
-    go_next = go;
+    if (lane == 0) go_next = go;
   }
   __syncthreads();
   if (go_next) embed_rows(p.e, b, tok_next, tid, blockDim.x);
