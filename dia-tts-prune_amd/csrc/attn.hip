@@ -214,6 +214,10 @@ template <typename KVT, int G>
 int launch_attn(const AttnK& k, int grid_y, int sc_ld, hipStream_t st) {
   size_t smem = sizeof(float) * ((size_t)G * HD + 2 * HD + 8 + (NT / 64) * G * HD + (size_t)G * sc_ld);
   if (smem > 160 * 1024) return dia_fail(DIA_E_ARG, "dia_attn: score buffer exceeds LDS");
+  if (smem > 64 * 1024) {
+    int rc = dia_kernels_init_once();
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL((k_attn<KVT, G>), dim3(k.n_kv_heads, grid_y), dim3(NT), smem, st, k);
   return dia_check_launch("k_attn");
 }

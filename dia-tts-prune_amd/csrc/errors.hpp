@@ -10,3 +10,5 @@ int dia_check_launch(const char* kernel);
 // one-time per-process kernel attribute setup (large dynamic LDS); called by dia_kernels_init()
 int dia_attn_init();
 int dia_sample_init();
+int dia_gemm_init();
+int dia_kernels_init_once();

@@ -6,18 +6,34 @@
 //
 // Mapping (CDNA4): one workgroup owns one 16-column strip of W and all of K; its NW waves split K
 // into contiguous ranges of KPW k-tiles.  A k-tile of the strip is one contiguous 1 KiB block
-// (64 lanes x 16 B) that is loaded straight into the B operand of v_mfma_f32_16x16x32_bf16 — no
-// LDS staging, no conversion (guide §5 'GEMV / M <= 16 decode weights').  All B loads of a wave
-// are issued before the first use, so a 16-wave workgroup keeps up to 64 KiB in flight.  X arrives
-// as three bf16 planes (hi+mid+lo == fp32 value); three MFMAs per k-tile accumulate them into one
-// fp32 accumulator, which makes the product exact w.r.t. the fp32 activations of the reference.
+// (64 lanes x 16 B) that is loaded (non-temporal: read once) straight into the B operand of
+// v_mfma_f32_16x16x32_bf16 — no LDS staging, no conversion (guide §5 'GEMV / M <= 16 decode
+// weights').  All B loads of a wave are issued before anything else.  X arrives as three bf16
+// planes (hi+mid+lo == fp32 value); three MFMAs per k-tile accumulate them into one fp32
+// accumulator, which makes the product exact w.r.t. the fp32 activations of the reference.
 // Cross-wave (split-K) partials are summed through LDS in a fixed order: results are
 // bit-reproducible run to run.
+//
+// Two kernels share the epilogue:
+//   k_gemm<MT,NW,KPW>       A fragments straight from L2 (any M; rows >= M alias the last valid row)
+//   k_gemv_small<NW,KPW,RS> M <= RS in {2,4} (batch 1-2): the few valid rows of X are staged ONCE per
+//                           workgroup into LDS in compact fragment order, so a wave issues 3*KT*4*RS/256
+//                           staging loads instead of 3*KPW full-wave fragment loads per wave — the
+//                           texture-address path, not HBM, bounded the direct form (measured 21.6 -> 14.5 us
+//                           on the 64 MiB wi_fused matrix with the A loads removed).
 #include "common.hpp"
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
+#include <cstdlib>
 
 namespace {
+
+// weights are read once per launch: non-temporal loads (measured 21.6 vs 26.2 us on wi_fused)
+#ifdef DIA_DBG_PLAIN_LOAD
+#define DIA_WLOAD(ptr) (*(ptr))
+#else
+#define DIA_WLOAD(ptr) __builtin_nontemporal_load(ptr)
+#endif
 
 struct GemmK {
   const bf16_raw* A; long a_plane_stride; int a_ktiles; int M;
@@ -29,6 +45,7 @@ struct GemmK {
   float* ssq_out;
   void* kc; void* vc; int kv_dtype; int kv_heads; int kv_cap; int kv_batch_index;
   const float* cos_t; const float* sin_t;
+  int spw;
 };
 
 __device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v) {
@@ -36,149 +53,42 @@ __device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float 
   else KVElem<bf16_raw>::store(reinterpret_cast<bf16_raw*>(base) + idx, v);
 }
 
-template <int MT, int NW, int KPW>
-__global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][MT][64]
-  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * MT * 64);   // [MT][16][17]
-  float* inv_s = tile + MT * 16 * 17;                                      // [MT*16]
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int strip = blockIdx.x;
-  const int mt0 = blockIdx.y * MT;                 // first m-tile of this group
-  const int kpw = (KPW > 0) ? KPW : (p.KT + NW - 1) / NW;
-  const int kt0 = w * kpw;
-
-  f32x4 acc[MT];
-  long aoff[MT];   // per m-tile element offset of this lane's A fragment at k-tile 0
+// Everything the epilogue needs from memory is requested early, behind the weight loads, so that its
+// latency overlaps theirs instead of adding dependent round trips at the end of the kernel.
+template <int MT, int NT>
+__device__ __forceinline__ void prefetch_epilogue(const GemmK& p, int tid, int mt0, int m, int n0, bool live,
+                                                  float* xpre, float* gpre, float* inv_s) {
+  if (p.epi == DIA_EPI_RESID_EMIT && live) {
+    const float* o = p.out + (long)m * p.ldo + n0;
+    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+    xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+    xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // rows >= M: the lane re-reads the last valid row of the (clamped) tile — same 16 B as its
-    // neighbour, so it costs no extra L2 traffic; its results are never stored
-    const int mtile = min(mt0 + i, (p.M - 1) >> 4);
-    const int rlast = min(15, p.M - 1 - mtile * 16);
-    const int alane = (lane & 48) | min(lane & 15, rlast);
-    aoff[i] = ((long)mtile * p.a_ktiles * 64 + alane) * 8;
+    for (int j = 0; j < 8; ++j) gpre[j] = p.gnext ? p.gnext[n0 + j] : 1.0f;
   }
-
-  const bf16x8* Wt = reinterpret_cast<const bf16x8*>(p.W) + ((long)strip * p.KT) * 64 + lane;
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-  // epilogue geometry (threads 0 .. MT*32-1: one row, 8 consecutive columns each)
-  const int e_mt = tid >> 5, e_r = (tid >> 1) & 15, half = tid & 1;
-  const int m = (mt0 + e_mt) * 16 + e_r;
-  const int n0 = strip * 16 + half * 8;
-  const bool e_thread = tid < MT * 32;
-  const bool live = e_thread && m < p.M;
-  float xpre[8], gpre[8];
-
-  auto prefetch_epilogue = [&]() {
-    // everything the epilogue needs from memory is requested now, behind the weight loads, so that
-    // its latency overlaps theirs instead of adding a dependent round trip at the end
-    if (p.epi == DIA_EPI_RESID_EMIT && live) {
-      const float* o = p.out + (long)m * p.ldo + n0;
-      const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
-      xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
-      xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) gpre[j] = p.gnext ? p.gnext[n0 + j] : 1.0f;
-    }
-    for (int t = tid; t < MT * 128; t += NW * 64) {       // 8 threads per row sum the strip partials
-      const int r = t >> 3, part = t & 7;
-      const int row = mt0 * 16 + r;
-      float sA = 0.f, sB = 0.f;
-      if (p.ssq_in != nullptr && row < p.M) {
-        int i = part;
-        for (; i + 8 < p.ssq_in_n; i += 16) {
-          sA += p.ssq_in[(long)i * p.ssq_ld + row];
-          sB += p.ssq_in[(long)(i + 8) * p.ssq_ld + row];
-        }
-        if (i < p.ssq_in_n) sA += p.ssq_in[(long)i * p.ssq_ld + row];
+  for (int t = tid; t < MT * 128; t += NT) {       // 8 threads per row sum the strip partials
+    const int r = t >> 3, part = t & 7;
+    const int row = mt0 * 16 + r;
+    float sA = 0.f, sB = 0.f;
+    if (p.ssq_in != nullptr && row < p.M) {
+      int i = part;
+      for (; i + 8 < p.ssq_in_n; i += 16) {
+        sA += p.ssq_in[(long)i * p.ssq_ld + row];
+        sB += p.ssq_in[(long)(i + 8) * p.ssq_ld + row];
       }
-      float sq = sA + sB;
-      sq += __shfl_xor(sq, 1, 64);
-      sq += __shfl_xor(sq, 2, 64);
-      sq += __shfl_xor(sq, 4, 64);
-      if (part == 0) inv_s[r] = (p.ssq_in != nullptr) ? rsqrtf(sq * p.inv_d + p.eps) : 1.0f;
+      if (i < p.ssq_in_n) sA += p.ssq_in[(long)i * p.ssq_ld + row];
     }
-  };
-
-  if constexpr (KPW > 0) {
-    bf16x8 b[KPW];
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) b[i] = __builtin_nontemporal_load(Wt + (long)(kt0 + i) * 64);
-    __builtin_amdgcn_sched_barrier(0);   // every HBM load of this wave is in flight before anything else
-    // k-tiles of A fetched up front (registers: 12*MT per k-tile; a 16-wave workgroup has 128 VGPRs)
-    constexpr int AP = (KPW >= 8) ? 1 : ((KPW * MT <= 4) ? KPW : ((4 / MT) > 0 ? (4 / MT) : 1));
-    bf16x8 a0[AP][MT][DIA_NPLANES];
-#pragma unroll
-    for (int i = 0; i < AP; ++i)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int pl = 0; pl < DIA_NPLANES; ++pl)
-          a0[i][mt][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt0 + i) * 512);
-    prefetch_epilogue();
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int pl = 0; pl < DIA_NPLANES; ++pl) {
-          bf16x8 a;
-          if (i < AP) a = a0[i < AP ? i : 0][mt][pl];
-          else a = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt0 + i) * 512);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
-        }
-      }
-    }
-  } else {
-    prefetch_epilogue();
-    const int kt1 = min(kt0 + kpw, p.KT);
-    for (int kt = kt0; kt < kt1; kt += 4) {
-      bf16x8 b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) b[i] = (kt + i < kt1) ? __builtin_nontemporal_load(Wt + (long)(kt + i) * 64) : zero8;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (kt + i < kt1) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int pl = 0; pl < DIA_NPLANES; ++pl) {
-              bf16x8 a = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt + i) * 512);
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
+    float sq = sA + sB;
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    sq += __shfl_xor(sq, 4, 64);
+    if (part == 0) inv_s[r] = (p.ssq_in != nullptr) ? rsqrtf(sq * p.inv_d + p.eps) : 1.0f;
   }
+}
 
-  // ---- split-K partials -> LDS, fixed-order sum by wave 0..MT-1
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) red[(w * MT + mt) * 64 + lane] = acc[mt];
-  __syncthreads();
-  if (tid < MT * 64) {
-    const int mt = tid >> 6;
-    f32x4 s = red[(0 * MT + mt) * 64 + lane];
-#pragma unroll
-    for (int ww = 1; ww < NW; ++ww) {
-      f32x4 t = red[(ww * MT + mt) * 64 + lane];
-      s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
-    }
-    const int col = lane & 15, r0 = (lane >> 4) * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tile[(mt * 16 + r0 + r) * 17 + col] = s[r];
-  }
-  __syncthreads();
-
-  // ---- epilogue: MT*32 threads, each 8 consecutive columns of one row
-  if (!e_thread) return;
-  const float* trow = tile + (e_mt * 16 + e_r) * 17;
-  const float inv = inv_s[e_mt * 16 + e_r];
-
+// One thread = one row x 8 consecutive columns of the finished 16x16 tile.
+__device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, float inv, int m, int n0, int half,
+                                             int strip, bool live, const float* xpre, const float* gpre) {
   if (p.epi == DIA_EPI_SCALE_STORE) {
     if (!live) return;
     float4 a = {trow[half * 8 + 0] * inv, trow[half * 8 + 1] * inv, trow[half * 8 + 2] * inv, trow[half * 8 + 3] * inv};
@@ -235,6 +145,210 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
   }
 }
 
+// split-K partials -> LDS -> fixed-order sum -> 16x16 tile(s) in LDS
+template <int MT, int NW>
+__device__ __forceinline__ void reduce_to_tile(const f32x4* acc, f32x4* red, float* tile, int tid, int lane, int w) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) red[(w * MT + mt) * 64 + lane] = acc[mt];
+  __syncthreads();
+  if (tid < MT * 64) {
+    const int mt = tid >> 6;
+    f32x4 s = red[(0 * MT + mt) * 64 + lane];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {
+      f32x4 t = red[(ww * MT + mt) * 64 + lane];
+      s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    }
+    const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(mt * 16 + r0 + r) * 17 + col] = s[r];
+  }
+  __syncthreads();
+}
+
+template <int MT, int NW, int KPW>
+__global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][MT][64]
+  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * MT * 64);   // [MT][16][17]
+  float* inv_s = tile + MT * 16 * 17;                                      // [MT*16]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int strip = blockIdx.x;
+  const int mt0 = blockIdx.y * MT;                 // first m-tile of this group
+  const int kpw = (KPW > 0) ? KPW : (p.KT + NW - 1) / NW;
+  const int kt0 = w * kpw;
+
+  f32x4 acc[MT];
+  long aoff[MT];   // per m-tile element offset of this lane's A fragment at k-tile 0
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // rows >= M: the lane re-reads the last valid row of the (clamped) tile — same 16 B as its
+    // neighbour, so it costs no extra L2 traffic; its results are never stored
+    const int mtile = min(mt0 + i, (p.M - 1) >> 4);
+    const int rlast = min(15, p.M - 1 - mtile * 16);
+    const int alane = (lane & 48) | min(lane & 15, rlast);
+    aoff[i] = ((long)mtile * p.a_ktiles * 64 + alane) * 8;
+  }
+
+  const bf16x8* Wt = reinterpret_cast<const bf16x8*>(p.W) + ((long)strip * p.KT) * 64 + lane;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // epilogue geometry (threads 0 .. MT*32-1: one row, 8 consecutive columns each)
+  const int e_mt = tid >> 5, e_r = (tid >> 1) & 15, half = tid & 1;
+  const int m = (mt0 + e_mt) * 16 + e_r;
+  const int n0 = strip * 16 + half * 8;
+  const bool e_thread = tid < MT * 32;
+  const bool live = e_thread && m < p.M;
+  float xpre[8], gpre[8];
+
+  if constexpr (KPW > 0) {
+    bf16x8 b[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) b[i] = DIA_WLOAD(Wt + (long)(kt0 + i) * 64);
+    __builtin_amdgcn_sched_barrier(0);   // every HBM load of this wave is in flight before anything else
+    // k-tiles of A fetched up front (registers: 12*MT per k-tile; a 16-wave workgroup has 128 VGPRs)
+    constexpr int AP = (KPW >= 8) ? 1 : ((KPW * MT <= 4) ? KPW : ((4 / MT) > 0 ? (4 / MT) : 1));
+    bf16x8 a0[AP][MT][DIA_NPLANES];
+#pragma unroll
+    for (int i = 0; i < AP; ++i)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < DIA_NPLANES; ++pl)
+          a0[i][mt][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt0 + i) * 512);
+    prefetch_epilogue<MT, NW * 64>(p, tid, mt0, m, n0, live, xpre, gpre, inv_s);
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+          bf16x8 a;
+          if (i < AP) a = a0[i < AP ? i : 0][mt][pl];
+          else a = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt0 + i) * 512);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    prefetch_epilogue<MT, NW * 64>(p, tid, mt0, m, n0, live, xpre, gpre, inv_s);
+    const int kt1 = min(kt0 + kpw, p.KT);
+    for (int kt = kt0; kt < kt1; kt += 4) {
+      bf16x8 b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = (kt + i < kt1) ? DIA_WLOAD(Wt + (long)(kt + i) * 64) : zero8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (kt + i < kt1) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+              bf16x8 a = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt + i) * 512);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  reduce_to_tile<MT, NW>(acc, red, tile, tid, lane, w);
+  if (!e_thread) return;
+  run_epilogue(p, tile + (e_mt * 16 + e_r) * 17, inv_s[e_mt * 16 + e_r], m, n0, half, strip, live, xpre, gpre);
+}
+
+// M <= RS rows (RS = 2 or 4): the valid rows of all three planes are staged once per workgroup into
+// LDS as [plane][ktile][kq 0..3][row 0..RS-1] x 16 B; lane l of a wave then reads its A fragment for
+// k-tile kt at ((plane*KT + kt)*4 + (l>>4))*RS + min(l&15, RS-1) (rows >= RS alias row RS-1: broadcast).
+template <int NW, int KPW, int RS, bool MULTI>
+__global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][64]
+  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * 64);   // [16][17]
+  float* inv_s = tile + 16 * 17;                                           // [16]
+  bf16x8* As = reinterpret_cast<bf16x8*>(smem_raw + sizeof(f32x4) * NW * 64 + sizeof(float) * (16 * 17 + 16));
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kt0 = w * KPW;
+  const int G = gridDim.x;                 // the workgroup walks strips blockIdx.x, +G, +2G, ...
+  const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + (long)kt0 * 64 + lane;
+  auto load_strip = [&](bf16x8* b, int strip) {
+    const bf16x8* Wt = Wl + (long)strip * p.KT * 64;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) b[i] = DIA_WLOAD(Wt + (long)i * 64);
+  };
+
+  bf16x8 b0[KPW], b1[MULTI ? KPW : 1];
+  load_strip(b0, blockIdx.x);
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int e_r = (tid >> 1) & 15, half = tid & 1;
+  const int m = e_r;
+  const bool e_thread = tid < 32;
+  const bool live = e_thread && m < p.M;
+  float xpre[8], gpre[8];
+
+  // ---- stage the compact A (L2-resident, tiny) once: chunk c = ((plane*KT + kt)*4 + kq)*RS + row
+  constexpr int NT = NW * 64;
+  constexpr int CH = 4;                               // chunks in flight per thread per round
+  const int nchunks = DIA_NPLANES * p.KT * 4 * RS;
+  for (int c0 = tid; c0 < nchunks; c0 += NT * CH) {
+    bf16x8 v[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int c = min(c0 + u * NT, nchunks - 1);
+      const int row = c % RS, kq = (c / RS) & 3, kt = (c / (4 * RS)) % p.KT, pl = c / (4 * RS * p.KT);
+      v[u] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)kt * 64 + row + 16 * kq) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (c0 + u * NT < nchunks) As[c0 + u * NT] = v[u];
+  }
+  // row scales (same rows for every strip) + first strip's residual operands
+  prefetch_epilogue<1, NT>(p, tid, 0, m, blockIdx.x * 16 + half * 8, live, xpre, gpre, inv_s);
+  __syncthreads();
+
+  const int arow = min(lane & 15, RS - 1), akq = lane >> 4;
+  auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
+    const int next = strip + G;
+    if constexpr (MULTI) { if (next < p.nstrips) load_strip(bn, next); }     // next strip's weights stream while this one computes
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+        const bf16x8 a = As[((pl * p.KT + kt0 + i) * 4 + akq) * RS + arow];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bc[i], acc[0], 0, 0, 0);
+      }
+    }
+    reduce_to_tile<1, NW>(acc, red, tile, tid, lane, w);
+    if (e_thread) {
+      const int n0 = strip * 16 + half * 8;
+      run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
+      if (MULTI && next < p.nstrips && p.epi == DIA_EPI_RESID_EMIT && live) {      // residual operands of the next strip
+        const int n1 = next * 16 + half * 8;
+        const float* o = p.out + (long)m * p.ldo + n1;
+        const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+        xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+        xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gpre[j] = p.gnext ? p.gnext[n1 + j] : 1.0f;
+      }
+    }
+  };
+  if constexpr (MULTI) {
+    for (int strip = blockIdx.x; strip < p.nstrips; strip += 2 * G) {
+      body(b0, b1, strip);
+      if (strip + G < p.nstrips) body(b1, b0, strip + G);
+    }
+  } else {
+    body(b0, b1, blockIdx.x);
+  }
+}
+
 template <int MT, int NW, int KPW>
 int launch(const GemmK& k, int mgroups, hipStream_t st) {
   size_t smem = sizeof(f32x4) * NW * MT * 64 + sizeof(float) * (MT * 16 * 17 + MT * 16);
@@ -268,7 +382,82 @@ int launch_nw(const GemmK& k, int nw, int mgroups, hipStream_t st) {
   }
 }
 
+size_t small_smem(int nw, int KT, int rs) {
+  return sizeof(f32x4) * nw * 64 + sizeof(float) * (16 * 17 + 16) + (size_t)DIA_NPLANES * KT * 4 * rs * 16;
+}
+
+template <int NW, int KPW, int RS>
+int launch_small(const GemmK& k, hipStream_t st) {
+  size_t smem = small_smem(NW, k.KT, RS);
+  if (const char* pad = getenv("DIA_DBG_LDS_PAD")) smem += (size_t)atoi(pad) * 1024;   // experiments: throttle residency
+  if (smem > 64 * 1024) {
+    int rc = dia_kernels_init_once();     // raises the dynamic-LDS limit of every large-LDS kernel, once
+    if (rc) return rc;
+  }
+  // strips per workgroup: enough workgroups to cover every CU, few enough that each streams several
+  // strips back to back (next strip's loads overlap this strip's reduce + epilogue)
+  int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
+  if (const char* e = getenv("DIA_DBG_SPW")) spw = atoi(e);
+  const int grid = (k.nstrips + spw - 1) / spw;
+  if (spw > 1) {
+    if constexpr (KPW <= 16 && !(NW == 16 && KPW > 4))
+      hipLaunchKernelGGL((k_gemv_small<NW, KPW, RS, true>), dim3(grid), dim3(NW * 64), smem, st, k);
+    else
+      hipLaunchKernelGGL((k_gemv_small<NW, KPW, RS, false>), dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+  } else {
+    hipLaunchKernelGGL((k_gemv_small<NW, KPW, RS, false>), dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+  }
+  return dia_check_launch("k_gemv_small");
+}
+
+template <int RS>
+int launch_small_rs(const GemmK& k, int nw, hipStream_t st, bool& handled) {
+  handled = true;
+  const int kpw = (k.KT % nw == 0) ? k.KT / nw : 0;
+  if (nw == 4) {
+    if (kpw == 4) return launch_small<4, 4, RS>(k, st);
+    if (kpw == 8) return launch_small<4, 8, RS>(k, st);
+    if (kpw == 16) return launch_small<4, 16, RS>(k, st);
+  } else if (nw == 8) {
+    if (kpw == 2) return launch_small<8, 2, RS>(k, st);
+    if (kpw == 4) return launch_small<8, 4, RS>(k, st);
+    if (kpw == 8) return launch_small<8, 8, RS>(k, st);
+    if (kpw == 16) return launch_small<8, 16, RS>(k, st);
+    if (kpw == 32) return launch_small<8, 32, RS>(k, st);
+  } else if (nw == 16) {
+    if (kpw == 1) return launch_small<16, 1, RS>(k, st);
+    if (kpw == 2) return launch_small<16, 2, RS>(k, st);
+    if (kpw == 4) return launch_small<16, 4, RS>(k, st);
+    if (kpw == 8) return launch_small<16, 8, RS>(k, st);
+  }
+  handled = false;
+  return DIA_OK;
+}
+
+template <int NW, int KPW>
+int small_attr() {
+  hipError_t e[4];
+  e[0] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  e[1] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  e[2] = e[3] = hipSuccess;
+  if constexpr (KPW <= 16 && !(NW == 16 && KPW > 4)) {
+    e[2] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e[3] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  for (int i = 0; i < 4; ++i) if (e[i] != hipSuccess) return dia_fail_hip(e[i], "hipFuncSetAttribute(k_gemv_small)");
+  return DIA_OK;
+}
+
 }  // namespace
+
+// large-LDS attribute of every small-M instantiation, set once outside any graph capture
+int dia_gemm_init() {
+  int rc = 0;
+  rc |= small_attr<4, 4>(); rc |= small_attr<4, 8>(); rc |= small_attr<4, 16>();
+  rc |= small_attr<8, 2>(); rc |= small_attr<8, 4>(); rc |= small_attr<8, 8>(); rc |= small_attr<8, 16>(); rc |= small_attr<8, 32>();
+  rc |= small_attr<16, 1>(); rc |= small_attr<16, 2>(); rc |= small_attr<16, 4>(); rc |= small_attr<16, 8>();
+  return rc ? DIA_E_HIP : DIA_OK;
+}
 
 extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W) return dia_fail(DIA_E_ARG, "dia_gemm: null argument");
@@ -293,20 +482,29 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   k.out = a->out; k.ldo = a->ldo; k.gnext = a->gnext;
   k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles; k.ssq_out = a->ssq_out;
   k.kc = a->kc; k.vc = a->vc; k.kv_dtype = a->kv_dtype; k.kv_heads = a->kv_heads; k.kv_cap = a->kv_cap;
-  k.kv_batch_index = a->kv_batch_index; k.cos_t = a->cos_t; k.sin_t = a->sin_t;
+  k.kv_batch_index = a->kv_batch_index; k.cos_t = a->cos_t; k.sin_t = a->sin_t; k.spw = a->spw;
 
   int nw = a->nw;
   if (nw == 0) {
     // many strips -> few fat waves (deep load queues); few strips -> many waves per strip.
     // A 16-wave workgroup has 128 VGPRs per lane: it keeps at most 8 weight tiles (32 VGPRs) in flight
     // per wave; longer K ranges go to 8-wave workgroups (256 VGPRs).
-    if (a->nstrips >= 512 && a->KT % 4 == 0 && a->KT / 4 <= 32) nw = 4;
+    if (a->M <= 4 && a->nstrips >= 1024 && a->KT % 16 == 0 && a->KT / 16 <= 4) nw = 16;   // persistent multi-strip form
+    else if (a->nstrips >= 512 && a->KT % 4 == 0 && a->KT / 4 <= 32) nw = 4;
     else if (a->KT % 16 == 0 && a->KT / 16 <= 8) nw = 16;
     else if (a->KT % 8 == 0) nw = 8;
     else nw = 4;
   }
   const int mtiles = (a->M + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
+  if (a->M <= 4 && a->epi != DIA_EPI_CROSSKV) {
+    const int rs = a->M <= 2 ? 2 : 4;
+    if (small_smem(nw, a->KT, rs) <= 150 * 1024) {
+      bool handled = false;
+      int rc = (rs == 2) ? launch_small_rs<2>(k, nw, st, handled) : launch_small_rs<4>(k, nw, st, handled);
+      if (handled) return rc;
+    }
+  }
   if (mtiles == 1) return launch_nw<1>(k, nw, 1, st);
   if (mtiles == 2) return launch_nw<2>(k, nw, 1, st);
   return launch_nw<4>(k, nw, (mtiles + 3) / 4, st);

@@ -379,6 +379,10 @@ extern "C" int dia_sample(const dia_sample_args* a, void* stream) {
   int rc = fill_embed(&ea, k.e);
   if (rc) return rc;
   const size_t smem = (size_t)a->C * (3 * VCAP) * sizeof(float);
+  if (smem > 64 * 1024) {
+    rc = dia_kernels_init_once();
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_sample, dim3(a->B), dim3(a->C * 64), smem, (hipStream_t)stream, k);
   return dia_check_launch("k_sample");
 }

@@ -12,7 +12,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdia_hip.so")
+LIB_PATH = os.environ.get("DIA_HIP_LIB") or os.path.join(_HERE, "libdia_hip.so")   # override: experiments only
 
 ABI_VERSION = 1
 KV_F32, KV_BF16 = 0, 1
@@ -21,7 +21,7 @@ ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
 
 EXPORTS = (
     "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_attn", "dia_enc_kv_prep",
-    "dia_embed_text", "dia_embed_tokens", "dia_sample", "dia_engine_create", "dia_engine_destroy",
+    "dia_embed_text", "dia_embed_tokens", "dia_sample", "dia_prefetch", "dia_engine_create", "dia_engine_destroy",
     "dia_engine_decode", "dia_engine_step_logits_only", "dia_engine_profile_step", "dia_engine_launches_per_step",
 )
 
@@ -35,7 +35,7 @@ class GemmArgs(C.Structure):
         ("A", C.c_void_p), ("a_plane_stride", C.c_int64), ("a_ktiles", C.c_int32), ("M", C.c_int32),
         ("W", C.c_void_p), ("KT", C.c_int32), ("nstrips", C.c_int32), ("epi", C.c_int32), ("nw", C.c_int32),
         ("ssq_in", C.c_void_p), ("ssq_in_n", C.c_int32), ("ssq_ld", C.c_int32), ("inv_d", C.c_float), ("eps", C.c_float),
-        ("out", C.c_void_p), ("ldo", C.c_int32), ("_pad0", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int32), ("spw", C.c_int32),
         ("gnext", C.c_void_p), ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("_pad1", C.c_int32),
         ("ssq_out", C.c_void_p),
         ("kc", C.c_void_p), ("vc", C.c_void_p), ("kv_dtype", C.c_int32), ("kv_heads", C.c_int32), ("kv_cap", C.c_int32),
@@ -140,6 +140,7 @@ def lib() -> C.CDLL:
                                  C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.dia_embed_tokens.argtypes = [C.POINTER(EmbedArgs), C.c_void_p]
     L.dia_sample.argtypes = [C.POINTER(SampleArgs), C.c_void_p]
+    L.dia_prefetch.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     L.dia_engine_create.argtypes = [C.POINTER(EngineDesc), C.c_void_p, C.POINTER(C.c_void_p)]
     L.dia_engine_destroy.argtypes = [C.c_void_p]
     L.dia_engine_decode.argtypes = [C.c_void_p, C.c_int, C.c_int]

@@ -72,7 +72,7 @@ typedef struct {
   float eps;
   float* out;               /* SCALE_STORE: [M][ldo]; RESID_EMIT: x in/out [M][ldo] */
   int32_t ldo;
-  int32_t _pad0;
+  int32_t spw;              /* strips per workgroup for the M <= 4 kernel; 0 = choose */
   const float* gnext;       /* RESID_EMIT: norm weight of the consumer (NULL -> 1) */
   void* P;                  /* emitted planes (RESID_EMIT, SWIGLU_EMIT) */
   int64_t p_plane_stride;
@@ -175,6 +175,10 @@ typedef struct {
   dia_embed_args embed;     /* next-step embedding; embed.tokens/cur are taken from above */
 } dia_sample_args;
 int dia_sample(const dia_sample_args* a, void* stream);
+
+/* Read-only pass over [ptr, ptr+nbytes) that pulls it into the 256 MiB Infinity Cache ahead of its
+ * consumer (weights of the next kernels of the decode chain); writes nothing. */
+int dia_prefetch(const void* ptr, int64_t nbytes, int nblocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Engine: owns nothing but the launch sequence.  All memory is allocated by the caller.

@@ -1,0 +1,52 @@
+"""micro-benchmark of dia_gemm on decode shapes: 18 distinct weight buffers (HBM-cold like a real step)"""
+import argparse, ctypes as C, sys, os, time
+sys.path.insert(0, "dia-tts-prune_amd")
+import torch
+from dia_hip import binding as hb, layout as lay
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shape", default="wi")
+ap.add_argument("--nw", type=int, default=0)
+ap.add_argument("--M", type=int, default=2)
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--prefetch", type=int, default=0)
+ap.add_argument("--same", type=int, default=0)
+a = ap.parse_args()
+d = torch.device("cuda:0")
+K, N, epi = {"wi": (2048, 16384, hb.EPI_SWIGLU_EMIT), "wo": (8192, 2048, hb.EPI_RESID_EMIT), "o": (2048, 2048, hb.EPI_RESID_EMIT),
+             "qkv": (2048, 3072, hb.EPI_SCALE_STORE), "logits": (2048, 9264, hb.EPI_SCALE_STORE)}[a.shape]
+M = a.M
+mpad = (M + 15) // 16 * 16
+Ws = [torch.randint(-30000, 30000, (N // 16, K // 32, 64, 8), dtype=torch.int16, device=d).view(torch.bfloat16) for _ in range(18)]
+x = torch.randn(M, K, device=d)
+A = lay.pack_planes(x)
+ssq = torch.ones(K // 16, mpad, device=d)
+out = torch.zeros(mpad, max(N, 16), device=d)
+P = torch.zeros(3, mpad // 16, max(N // 32, 1) if epi != hb.EPI_SWIGLU_EMIT else N // 64, 64, 8, dtype=torch.bfloat16, device=d)
+ssq_out = torch.zeros(N // 16, mpad, device=d)
+gn = torch.ones(N, device=d)
+L = hb.lib()
+st = torch.cuda.Stream()
+def launch(W):
+    g = hb.GemmArgs()
+    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+    g.W, g.KT, g.nstrips, g.epi, g.nw = hb.ptr(W), K // 32, N // 16, epi, a.nw
+    if epi != hb.EPI_RESID_EMIT:
+        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq), K // 16, 1.0 / K, 1e-5
+    g.ssq_ld = mpad
+    g.out, g.ldo, g.gnext = hb.ptr(out), out.shape[1], hb.ptr(gn)
+    g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), P.shape[2], hb.ptr(ssq_out)
+    hb.check(L.dia_gemm(C.byref(g), C.c_void_p(st.cuda_stream)), "gemm")
+if a.same: Ws = Ws[:1] * 18
+for W in Ws: launch(W)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(st)
+for _ in range(a.reps):
+    for W in Ws:
+        if a.prefetch:
+            hb.check(L.dia_prefetch(hb.ptr(W), W.numel() * 2, a.prefetch, C.c_void_p(st.cuda_stream)), "prefetch")
+        launch(W)
+e1.record(st); st.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / (a.reps * 18)
+print(f"{a.shape} M={M} nw={a.nw}: {us:.2f} us/launch (back-to-back incl. gaps), {K*N*2/us/1e3:.0f} GB/s")
