@@ -150,15 +150,19 @@ def main():
         breakdown = {LAUNCH_NAMES[i]: round(float(kind_ms[i]) * 1e3, 2) for i in range(8)}
         breakdown["logits"] = round(float(prof[:, nl * 8].mean()) * 1e3, 2)
         breakdown["sample_fsm_embed"] = round(float(prof[:, nl * 8 + 1].mean()) * 1e3, 2)
-        breakdown["unit"] = "us per launch (eager, event-bracketed)"
-        wi_ms = float(kind_ms[6])
+        breakdown["unit"] = "us between per-launch HIP events of one eager step (each interval carries ~3 us of event/boundary overhead)"
+        wi_ms = sess.time_wi_launches(reps=5) * 1e3          # dispatch-level start/stop events per launch
         wi_bytes = w.dec_layers[0]["wi"].nbytes                  # algorithmic bytes of the dominant kernel
-        roof = {"bound": "hbm", "kernel": "k_gemm<MT=1,NW=4,KPW=16> (wi_fused GEMV, SwiGLU epilogue)",
+        kname = ("k_gemv_small<NW=16,KPW=4,RS=%d,MULTI>" % (2 if 2 * args.batch <= 2 else 4)) if 2 * args.batch <= 4 \
+            else "k_gemm<MT=%d,NW=4,KPW=16>" % min(4, (2 * args.batch + 15) // 16)
+        roof = {"bound": "hbm", "kernel": kname + " on wi_fused [2048 x 16384] bf16 (SwiGLU epilogue), 18 launches/step",
                 "achieved": round(wi_bytes / (wi_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(wi_bytes / (wi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "bytes_per_launch": wi_bytes, "us_per_launch": round(wi_ms * 1e3, 2), "traffic": None}
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled
+        # as the gfx950 guide prescribes); measured offline, committed under profiles/
         tr = os.path.join(ROOT, "profiles", "traffic_wi.json")
-        if os.path.isfile(tr):
+        if os.path.isfile(tr) and args.batch == 1:
             try:
                 roof["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
             except Exception:

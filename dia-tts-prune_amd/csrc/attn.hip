@@ -1,16 +1,19 @@
-// Single-query attention for the decode path, head_dim 128, fp32 arithmetic.
+// Single-query attention for the decode path, head_dim 128, fp32 arithmetic, split over the keys.
 //
 // Replaces, per reference call site: RotaryEmbedding.forward on q and the new k (dia/layers.py:135-173,
 // 278-279), KVCache.update (dia/state.py:99-103), the GQA repeat_interleave (layers.py:319-320, never
 // materialised here: one workgroup serves a kv head and its `G` query heads) and
 // F.scaled_dot_product_attention (layers.py:329-337).
 //
-// One workgroup = (kv head, query row).  Two passes over the keys:
-//   pass 1  16 lanes per key (8 dims each, one 16 B load for bf16 K / two for fp32), G dot products,
-//           xor-butterfly over the 16 lanes, score -> LDS
-//   softmax one wave per query head: max, exp, sum (the 1/sum is applied once at the end)
-//   pass 2  same key->lane-group mapping on V, p from LDS, partial outputs reduced over the 4 groups
-//           of a wave by shuffles and over the waves through LDS in a fixed order (deterministic).
+// Grid = (kv head, query row, key chunk).  A workgroup owns CHUNK = 128 consecutive keys of one
+// (row, kv head): 16 lanes per key (8 dims each, one 16 B load for bf16 K / two for fp32), four keys
+// per lane group with all loads in flight at once, G dot products, xor-butterfly over the 16 lanes,
+// chunk-local softmax numerators in LDS, then P.V with the same key->lane-group mapping, reduced over
+// the lane groups by shuffles and LDS in a fixed order.  A (row, head) with one active chunk emits
+// directly.  With several, every chunk publishes {max, sum, unnormalised output} to a scratch slab and
+// the LAST arriver (agent-scope release / ticket / acquire, guide §6 G16) merges the slabs in chunk
+// order — deterministic regardless of arrival order — and emits.  The grid is static (hipGraph): chunks
+// beyond the current length exit at once.
 // The output leaves as three bf16 planes in MFMA A-operand order for the o_proj GEMM.
 #include "common.hpp"
 #include "../../include/dia_hip.h"
@@ -21,7 +24,9 @@ namespace {
 constexpr int HD = 128;
 constexpr int NT = 512;            // threads per workgroup
 constexpr int NGRP = NT / 16;      // key groups
-constexpr int U = 4;               // keys per lane group per round (independent loads in flight)
+constexpr int U = 4;               // keys per lane group (independent loads in flight)
+constexpr int CHUNK = NGRP * U;    // 128 keys per workgroup
+constexpr int SLAB = 2 * 8 + 4 * HD;   // floats per (row, head, chunk): m[G<=4], l[G<=4] (padded to 8 each), o[G][128]
 
 struct AttnK {
   int mode, n_kv_heads, n_rows, kv_cap;
@@ -30,35 +35,39 @@ struct AttnK {
   const int* cur; const int* len; int enc_len;
   const float* cos_t; const float* sin_t;
   bf16_raw* P; long p_plane_stride; int p_ktiles;
+  float* scratch; int* tickets; int max_chunks;
 };
 
 template <typename KVT, int G>
 __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* q_s = smem;                       // [G][128]
-  float* knew = q_s + G * HD;              // [128]
-  float* vnew = knew + HD;                 // [128]
-  float* lsum = vnew + HD;                 // [G] (padded to 8)
-  float* part = lsum + 8;                  // [NT/64][G][128]
-  float* sc = part + (NT / 64) * G * HD;   // [G][nkeys_cap]
+  __shared__ __attribute__((aligned(16))) float q_s[G * HD];
+  __shared__ float sc[G * CHUNK];
+  __shared__ float part[(NT / 64) * G * HD];
+  __shared__ float m_s[8], l_s[8];
+  __shared__ int last_s;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int kvh = blockIdx.x;
-  int qrow, kvrow, pos, nkeys, slot = -1;
+  const int kvh = blockIdx.x, chunk = blockIdx.z;
+  int qrow, kvrow, pos, nkeys, slot = -1, head_row;
   if (p.mode == DIA_ATTN_SELF) {
     qrow = blockIdx.y; kvrow = qrow;
     const int c = p.cur[qrow >> 1];
     pos = c; nkeys = c; slot = c - 1;
+    head_row = qrow;
   } else if (p.mode == DIA_ATTN_CROSS) {
     const int b = blockIdx.y;
     qrow = 2 * b + 1; kvrow = b;
     pos = p.cur[b]; nkeys = p.len[b];
+    head_row = b;
   } else {
     qrow = blockIdx.y; kvrow = 0; pos = qrow; nkeys = p.enc_len;
+    head_row = qrow;
   }
-  const int sc_ld = (p.mode == DIA_ATTN_ENC) ? p.enc_len : p.kv_cap;
+  const int nchunks = max(1, (nkeys + CHUNK - 1) / CHUNK);
+  if (chunk >= nchunks) return;                       // uniform: nothing to do for this chunk yet
+  const int k0 = chunk * CHUNK, k1 = min(nkeys, k0 + CHUNK);
 
-  // ---- prologue: RoPE(q) (and RoPE(k_new), v_new -> cache) ------------------------------------
+  // ---- prologue: RoPE(q); the chunk that owns the new slot also ropes k and appends k, v ---------
   const float* qr = p.q + (long)qrow * p.ldq;
   for (int t = tid; t < G * 64; t += NT) {
     const int g = t >> 6, d = t & 63;
@@ -70,22 +79,20 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
   }
   KVT* Kc = reinterpret_cast<KVT*>(p.kc) + ((long)kvrow * p.n_kv_heads + kvh) * p.kv_cap * HD;
   KVT* Vc = reinterpret_cast<KVT*>(p.vc) + ((long)kvrow * p.n_kv_heads + kvh) * p.kv_cap * HD;
-  if (p.mode == DIA_ATTN_SELF && tid >= NT - 64) {
+  if (p.mode == DIA_ATTN_SELF && slot >= k0 && slot < k1 && tid >= NT - 64) {
     const int d = tid - (NT - 64);
     const float* kh = qr + p.k_off + kvh * HD;
     const float* vh = qr + p.v_off + kvh * HD;
     const float x1 = kh[d], x2 = kh[d + 64];
     const float c = p.cos_t[(long)pos * 64 + d], s = p.sin_t[(long)pos * 64 + d];
-    const float k1 = KVElem<KVT>::round(x1 * c - x2 * s), k2 = KVElem<KVT>::round(x1 * s + x2 * c);
-    const float v1 = KVElem<KVT>::round(vh[d]), v2 = KVElem<KVT>::round(vh[d + 64]);
-    KVElem<KVT>::store(Kc + (long)slot * HD + d, k1);
-    KVElem<KVT>::store(Kc + (long)slot * HD + d + 64, k2);
-    KVElem<KVT>::store(Vc + (long)slot * HD + d, v1);
-    KVElem<KVT>::store(Vc + (long)slot * HD + d + 64, v2);
+    KVElem<KVT>::store(Kc + (long)slot * HD + d, x1 * c - x2 * s);
+    KVElem<KVT>::store(Kc + (long)slot * HD + d + 64, x1 * s + x2 * c);
+    KVElem<KVT>::store(Vc + (long)slot * HD + d, vh[d]);
+    KVElem<KVT>::store(Vc + (long)slot * HD + d + 64, vh[d + 64]);
   }
-  __syncthreads();
+  __syncthreads();     // orders the append before this workgroup's reads of that slot
 
-  // ---- pass 1: scores -------------------------------------------------------------------------
+  // ---- scores: lane group grp handles keys k0 + grp + u*NGRP --------------------------------------
   const int grp = tid >> 4, sub = tid & 15;
   float qreg[G][8];
 #pragma unroll
@@ -93,15 +100,14 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) qreg[g][j] = q_s[g * HD + sub * 8 + j];
   const float scale = 0.08838834764831845f;   // 1/sqrt(128)
-  // U keys per lane group per round, all U loads issued before the first use.  The key written by
-  // this workgroup in the prologue is read back from memory like any other (the barrier above orders it).
-  for (int key0 = grp; key0 < nkeys; key0 += NGRP * U) {
+  const int klast = max(k1 - 1, k0);
+  {
     float kv[U][8];
 #pragma unroll
-    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Kc + (long)min(key0 + u * NGRP, nkeys - 1) * HD + sub * 8, kv[u]);
+    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Kc + (long)min(k0 + grp + u * NGRP, klast) * HD + sub * 8, kv[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int key = key0 + u * NGRP;
+      const int kl = grp + u * NGRP;             // key index inside the chunk
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         float s = 0.f;
@@ -111,48 +117,42 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
         s += __shfl_xor(s, 4, 64);
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 1, 64);
-        if (sub == 0 && key < nkeys) sc[g * sc_ld + key] = s * scale;
+        if (sub == 0) sc[g * CHUNK + kl] = (k0 + kl < k1) ? s * scale : -INFINITY;
       }
     }
   }
+  // V loads are independent of the softmax: request them now
+  float vv[U][8];
+#pragma unroll
+  for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Vc + (long)min(k0 + grp + u * NGRP, klast) * HD + sub * 8, vv[u]);
   __syncthreads();
 
-  // ---- softmax numerators (wave g handles query head g) ------------------------------------------
+  // ---- chunk-local softmax numerators (wave g handles query head g) --------------------------------
   if (w < G) {
-    float* s = sc + w * sc_ld;
-    float m = -INFINITY;
-    for (int k = lane; k < nkeys; k += 64) m = fmaxf(m, s[k]);
-    m = wave_max(m);
-    float l = 0.f;
-    for (int k = lane; k < nkeys; k += 64) {
-      const float e = expf(s[k] - m);
-      s[k] = e;
-      l += e;
-    }
-    l = wave_sum(l);
-    if (lane == 0) lsum[w] = l;
+    float* s = sc + w * CHUNK;
+    const float a = s[lane], b = s[lane + 64];
+    const float m = wave_max(fmaxf(a, b));
+    const float ea = (nkeys > 0) ? expf(a - m) : 0.f, eb = (nkeys > 0) ? expf(b - m) : 0.f;   // exp(-inf) = 0 for padding keys
+    s[lane] = ea; s[lane + 64] = eb;
+    const float l = wave_sum(ea + eb);
+    if (lane == 0) { m_s[w] = m; l_s[w] = l; }
   }
   __syncthreads();
 
-  // ---- pass 2: P.V ----------------------------------------------------------------------------
+  // ---- P.V --------------------------------------------------------------------------------------
   float acc[G][8];
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
-  for (int key0 = grp; key0 < nkeys; key0 += NGRP * U) {
-    float vv[U][8];
 #pragma unroll
-    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Vc + (long)min(key0 + u * NGRP, nkeys - 1) * HD + sub * 8, vv[u]);
+  for (int u = 0; u < U; ++u) {
+    const int kl = grp + u * NGRP;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int key = key0 + u * NGRP;
+    for (int g = 0; g < G; ++g) {
+      const float pk = sc[g * CHUNK + kl];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float pk = key < nkeys ? sc[g * sc_ld + key] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[g][j] += pk * vv[u][j];
-      }
+      for (int j = 0; j < 8; ++j) acc[g][j] += pk * vv[u][j];
     }
   }
 #pragma unroll
@@ -172,19 +172,71 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
   }
   __syncthreads();
 
-  // ---- output: G*16 threads, 8 dims each; planes for the o_proj GEMM ---------------------------
-  if (tid < G * 16) {
-    const int g = tid >> 4, d0 = (tid & 15) * 8;
-    const float invl = lsum[g] > 0.f ? 1.0f / lsum[g] : 0.f;   // no keys (empty text) -> 0, like a fully masked row
-    float o[8];
+  // ---- G*16 threads own 8 output dims each: sum over the waves in fixed order -------------------------
+  const bool o_thread = tid < G * 16;
+  const int og = tid >> 4, od0 = (tid & 15) * 8;
+  float o[8];
+  if (o_thread) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float a = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < NT / 64; ++ww) a += part[(ww * G + g) * HD + d0 + j];
-      o[j] = a * invl;
+      for (int ww = 0; ww < NT / 64; ++ww) a += part[(ww * G + og) * HD + od0 + j];
+      o[j] = a;
     }
-    const int col = (kvh * G + g) * HD + d0;
+  }
+  float M = o_thread ? m_s[og] : 0.f, Lsum = o_thread ? l_s[og] : 1.f;
+
+  if (nchunks > 1) {
+    // publish this chunk's slab, take a ticket; the last arriver merges
+    const long pair = (long)head_row * p.n_kv_heads + kvh;
+    float* slab = p.scratch + (pair * p.max_chunks + chunk) * SLAB;
+    if (o_thread) {
+      if ((tid & 15) == 0) { slab[og] = M; slab[8 + og] = Lsum; }
+      *reinterpret_cast<float4*>(slab + 16 + og * HD + od0) = float4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<float4*>(slab + 16 + og * HD + od0 + 4) = float4{o[4], o[5], o[6], o[7]};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(p.tickets + pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == nchunks - 1;
+      if (last) {
+        __hip_atomic_store(p.tickets + pair, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      last_s = last;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    if (o_thread) {
+      const float* base = p.scratch + pair * p.max_chunks * SLAB;
+      float mm = -INFINITY;
+      for (int c = 0; c < nchunks; ++c) mm = fmaxf(mm, base[(long)c * SLAB + og]);
+      float L2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
+      for (int c = 0; c < nchunks; ++c) {                       // chunk order: deterministic
+        const float* sl = base + (long)c * SLAB;
+        const float f = expf(sl[og] - mm);
+        L2 += sl[8 + og] * f;
+        const float4 a = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0);
+        const float4 b = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0 + 4);
+        o[0] += a.x * f; o[1] += a.y * f; o[2] += a.z * f; o[3] += a.w * f;
+        o[4] += b.x * f; o[5] += b.y * f; o[6] += b.z * f; o[7] += b.w * f;
+      }
+      Lsum = L2;
+    }
+  }
+
+  if (o_thread) {
+    const float invl = Lsum > 0.f ? 1.0f / Lsum : 0.f;   // no keys (empty text) -> 0, like a fully masked row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] *= invl;
+    const int col = (kvh * G + og) * HD + od0;
     emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, qrow, col, o);
     if (p.mode == DIA_ATTN_CROSS) {
       // the uncond row's cross-attention mask is all False -> SDPA returns 0
@@ -211,58 +263,51 @@ __global__ void k_enc_kv_prep(const float* qkv, int ldq, int k_off, int v_off, i
 }
 
 template <typename KVT, int G>
-int launch_attn(const AttnK& k, int grid_y, int sc_ld, hipStream_t st) {
-  size_t smem = sizeof(float) * ((size_t)G * HD + 2 * HD + 8 + (NT / 64) * G * HD + (size_t)G * sc_ld);
-  if (smem > 160 * 1024) return dia_fail(DIA_E_ARG, "dia_attn: score buffer exceeds LDS");
-  if (smem > 64 * 1024) {
-    int rc = dia_kernels_init_once();
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL((k_attn<KVT, G>), dim3(k.n_kv_heads, grid_y), dim3(NT), smem, st, k);
+int launch_attn(const AttnK& k, int grid_y, int grid_z, hipStream_t st) {
+  hipLaunchKernelGGL((k_attn<KVT, G>), dim3(k.n_kv_heads, grid_y, grid_z), dim3(NT), 0, st, k);
   return dia_check_launch("k_attn");
-}
-
-template <typename KVT, int G>
-int set_attr() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn<KVT, G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  return e == hipSuccess ? DIA_OK : dia_fail_hip(e, "hipFuncSetAttribute(k_attn)");
 }
 
 }  // namespace
 
-int dia_attn_init() {
-  int rc = 0;
-  rc |= set_attr<float, 1>(); rc |= set_attr<float, 2>(); rc |= set_attr<float, 4>();
-  rc |= set_attr<bf16_raw, 1>(); rc |= set_attr<bf16_raw, 2>(); rc |= set_attr<bf16_raw, 4>();
-  return rc ? DIA_E_HIP : DIA_OK;
+int dia_attn_init() { return DIA_OK; }   // static LDS only since the split-key rewrite
+
+extern "C" int dia_attn_scratch_floats(int n_rows, int n_kv_heads, int kv_cap) {
+  const long chunks = (kv_cap + CHUNK - 1) / CHUNK;
+  const long n = (long)n_rows * n_kv_heads * chunks * SLAB;
+  return n > 0x7fffffffL ? -1 : (int)n;
 }
 
 extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
   if (!a || !a->q || !a->kc || !a->vc || !a->P || !a->cos_t || !a->sin_t) return dia_fail(DIA_E_ARG, "dia_attn: null argument");
   if (a->n_rows <= 0 || a->n_kv_heads <= 0) return dia_fail(DIA_E_ARG, "dia_attn: empty problem");
   if (a->p_plane_stride % 8 != 0) return dia_fail(DIA_E_ARG, "dia_attn: plane stride must be a multiple of 8");
+  const int cap_keys = a->mode == DIA_ATTN_ENC ? a->enc_len : a->kv_cap;
+  const int max_chunks = (cap_keys + CHUNK - 1) / CHUNK;
+  if (max_chunks > 1 && (!a->scratch || !a->tickets)) return dia_fail(DIA_E_ARG, "dia_attn: more than 128 keys possible: scratch and tickets are required");
   AttnK k;
   k.mode = a->mode; k.n_kv_heads = a->n_kv_heads; k.n_rows = a->n_rows; k.kv_cap = a->kv_cap;
   k.q = a->q; k.ldq = a->ldq; k.q_off = a->q_off; k.k_off = a->k_off; k.v_off = a->v_off;
   k.kc = a->kc; k.vc = a->vc; k.cur = a->cur; k.len = a->len; k.enc_len = a->enc_len;
   k.cos_t = a->cos_t; k.sin_t = a->sin_t;
   k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles;
+  k.scratch = a->scratch; k.tickets = a->tickets; k.max_chunks = (a->kv_cap + CHUNK - 1) / CHUNK;
   if ((a->n_kv_heads * a->group * 128 + 31) / 32 > a->p_ktiles) return dia_fail(DIA_E_ARG, "dia_attn: output planes too narrow");
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = a->kv_dtype == DIA_KV_F32;
   switch (a->mode) {
     case DIA_ATTN_SELF:
       if (!a->cur) return dia_fail(DIA_E_ARG, "dia_attn: SELF needs cur");
-      if (a->group == 4) return f32 ? launch_attn<float, 4>(k, a->n_rows, a->kv_cap, st) : launch_attn<bf16_raw, 4>(k, a->n_rows, a->kv_cap, st);
-      if (a->group == 2) return f32 ? launch_attn<float, 2>(k, a->n_rows, a->kv_cap, st) : launch_attn<bf16_raw, 2>(k, a->n_rows, a->kv_cap, st);
-      if (a->group == 1) return f32 ? launch_attn<float, 1>(k, a->n_rows, a->kv_cap, st) : launch_attn<bf16_raw, 1>(k, a->n_rows, a->kv_cap, st);
+      if (a->group == 4) return f32 ? launch_attn<float, 4>(k, a->n_rows, max_chunks, st) : launch_attn<bf16_raw, 4>(k, a->n_rows, max_chunks, st);
+      if (a->group == 2) return f32 ? launch_attn<float, 2>(k, a->n_rows, max_chunks, st) : launch_attn<bf16_raw, 2>(k, a->n_rows, max_chunks, st);
+      if (a->group == 1) return f32 ? launch_attn<float, 1>(k, a->n_rows, max_chunks, st) : launch_attn<bf16_raw, 1>(k, a->n_rows, max_chunks, st);
       return dia_fail(DIA_E_ARG, "dia_attn: GQA group must be 1, 2 or 4");
     case DIA_ATTN_CROSS:
       if (!a->cur || !a->len || a->group != 1) return dia_fail(DIA_E_ARG, "dia_attn: CROSS needs cur, len and group 1");
-      return f32 ? launch_attn<float, 1>(k, a->n_rows, a->kv_cap, st) : launch_attn<bf16_raw, 1>(k, a->n_rows, a->kv_cap, st);
+      return f32 ? launch_attn<float, 1>(k, a->n_rows, max_chunks, st) : launch_attn<bf16_raw, 1>(k, a->n_rows, max_chunks, st);
     case DIA_ATTN_ENC:
       if (a->group != 1 || a->enc_len <= 0 || a->enc_len > a->kv_cap || !f32) return dia_fail(DIA_E_ARG, "dia_attn: ENC needs group 1, fp32 scratch K/V, 0 < L <= cap");
-      return launch_attn<float, 1>(k, a->n_rows, a->enc_len, st);
+      return launch_attn<float, 1>(k, a->n_rows, max_chunks, st);
     default:
       return dia_fail(DIA_E_ARG, "dia_attn: unknown mode");
   }

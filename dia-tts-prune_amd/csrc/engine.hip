@@ -60,6 +60,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     a.n_rows = R; a.kv_cap = d.T; a.q = d.qkv; a.ldq = nqkv; a.q_off = 0; a.k_off = d.q_heads * 128;
     a.v_off = (d.q_heads + d.kv_heads) * 128; a.kc = L.k_self; a.vc = L.v_self; a.cur = d.sample.cur;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
+    a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
     if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
 
     // o_proj + residual; emits the pre-CA-normed planes (layers.py:341-343, 555, 560)
@@ -83,6 +84,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     a.n_rows = d.B; a.kv_cap = d.S; a.q = d.qc; a.ldq = d.cq_heads * 128; a.q_off = 0;
     a.kc = L.k_cross; a.vc = L.v_cross; a.cur = d.sample.cur; a.len = d.text_len;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
+    a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
     if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
 
     g = {};
@@ -129,7 +131,7 @@ extern "C" int dia_engine_create(const dia_engine_desc* d, void* stream, dia_eng
   if (d->rows_pad < 2 * d->B || d->rows_pad % 16 != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: rows_pad must be 16*ceil(2B/16)");
   if (d->q_heads % d->kv_heads != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: q_heads % kv_heads != 0");
   if (!d->x || !d->planes_x || !d->planes_a || !d->planes_h || !d->ssq || !d->qkv || !d->qc || !d->logits || !d->cos_t ||
-      !d->sin_t || !d->text_len || !d->w_logits || !d->g_final)
+      !d->sin_t || !d->text_len || !d->w_logits || !d->g_final || !d->attn_scratch || !d->attn_tickets)
     return dia_fail(DIA_E_ARG, "dia_engine_create: missing buffer");
   int rc = dia_kernels_init_once();
   if (rc) return rc;
@@ -182,6 +184,12 @@ extern "C" int dia_engine_step_logits_only(dia_engine* e) {
   return enqueue_step(e, false);
 }
 
+// bounded device-side wait (wall clock, 100 MHz): lets the host run ahead of the stream
+__global__ void k_delay(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 extern "C" int dia_engine_profile_step(dia_engine* e, float* ms, int cap) {
   if (!e || !ms) return dia_fail(DIA_E_ARG, "dia_engine_profile_step: null argument");
   const int n = e->d.n_layer * 8 + 2;
@@ -191,12 +199,21 @@ extern "C" int dia_engine_profile_step(dia_engine* e, float* ms, int cap) {
     hipError_t he = hipEventCreate(&ev);
     if (he != hipSuccess) return dia_fail_hip(he, "hipEventCreate");
   }
+  // Events inside a captured graph cannot be read back with hipEventElapsedTime on ROCm 7.2, so the
+  // step is launched eagerly BEHIND a ~3 ms device-side delay kernel: by the time the delay ends the
+  // host has queued every launch and event, and the intervals are device-side kernel time + the
+  // in-queue dependency gap (what a graph replay pays), not host launch latency.
+  int rc = DIA_OK;
+  hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, e->stream, 300000LL /* 100 MHz ticks = 3 ms */);
   (void)hipEventRecord(e->prof[0], e->stream);
-  int rc = enqueue_step(e, true);
-  hipError_t he = hipStreamSynchronize(e->stream);
-  if (rc == DIA_OK && he != hipSuccess) rc = dia_fail_hip(he, "hipStreamSynchronize");
+  rc = enqueue_step(e, true);
+  {
+    hipError_t he = hipStreamSynchronize(e->stream);
+    if (rc == DIA_OK && he != hipSuccess) rc = dia_fail_hip(he, "hipStreamSynchronize");
+  }
   if (rc == DIA_OK)
-    for (int i = 0; i < n; ++i) (void)hipEventElapsedTime(&ms[i], e->prof[i], e->prof[i + 1]);
+    for (int i = 0; i < n; ++i)
+      if (hipEventElapsedTime(&ms[i], e->prof[i], e->prof[i + 1]) != hipSuccess) { ms[i] = -1.f; (void)hipGetLastError(); }
   for (auto& ev : e->prof) (void)hipEventDestroy(ev);
   e->prof.clear();
   return rc;

@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 namespace {
@@ -34,6 +35,16 @@ namespace {
 #else
 #define DIA_WLOAD(ptr) __builtin_nontemporal_load(ptr)
 #endif
+
+// when set (dia_gemm_timed), the next launch is bracketed by these events via hipExtLaunchKernelGGL:
+// the timestamps come from the dispatch packet itself (kernel begin/end), like rocprofv3's durations
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+template <typename Kern, typename Arg>
+void launch_kernel(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream_t st, const Arg& arg) {
+  if (g_ev_start) hipExtLaunchKernelGGL(kern, grid, block, smem, st, g_ev_start, g_ev_stop, 0, arg);
+  else hipLaunchKernelGGL(kern, grid, block, smem, st, arg);
+}
 
 struct GemmK {
   const bf16_raw* A; long a_plane_stride; int a_ktiles; int M;
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
 template <int MT, int NW, int KPW>
 int launch(const GemmK& k, int mgroups, hipStream_t st) {
   size_t smem = sizeof(f32x4) * NW * MT * 64 + sizeof(float) * (MT * 16 * 17 + MT * 16);
-  hipLaunchKernelGGL((k_gemm<MT, NW, KPW>), dim3(k.nstrips, mgroups), dim3(NW * 64), smem, st, k);
+  launch_kernel(k_gemm<MT, NW, KPW>, dim3(k.nstrips, mgroups), dim3(NW * 64), smem, st, k);
   return dia_check_launch("k_gemm");
 }
 
@@ -401,11 +412,11 @@ int launch_small(const GemmK& k, hipStream_t st) {
   const int grid = (k.nstrips + spw - 1) / spw;
   if (spw > 1) {
     if constexpr (KPW <= 16 && !(NW == 16 && KPW > 4))
-      hipLaunchKernelGGL((k_gemv_small<NW, KPW, RS, true>), dim3(grid), dim3(NW * 64), smem, st, k);
+      launch_kernel(k_gemv_small<NW, KPW, RS, true>, dim3(grid), dim3(NW * 64), smem, st, k);
     else
-      hipLaunchKernelGGL((k_gemv_small<NW, KPW, RS, false>), dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+      launch_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips), dim3(NW * 64), smem, st, k);
   } else {
-    hipLaunchKernelGGL((k_gemv_small<NW, KPW, RS, false>), dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+    launch_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips), dim3(NW * 64), smem, st, k);
   }
   return dia_check_launch("k_gemv_small");
 }
@@ -508,4 +519,20 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   if (mtiles == 1) return launch_nw<1>(k, nw, 1, st);
   if (mtiles == 2) return launch_nw<2>(k, nw, 1, st);
   return launch_nw<4>(k, nw, (mtiles + 3) / 4, st);
+}
+
+extern "C" int dia_gemm_timed(const dia_gemm_args* a, void* stream, float* ms_out) {
+  if (!ms_out) return dia_fail(DIA_E_ARG, "dia_gemm_timed: null output");
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return dia_fail(DIA_E_HIP, "hipEventCreate");
+  g_ev_start = e0; g_ev_stop = e1;
+  int rc = dia_gemm(a, stream);
+  g_ev_start = g_ev_stop = nullptr;
+  if (rc == DIA_OK) {
+    hipError_t he = hipEventSynchronize(e1);
+    if (he == hipSuccess) he = hipEventElapsedTime(ms_out, e0, e1);
+    if (he != hipSuccess) rc = dia_fail_hip(he, "dia_gemm_timed");
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
 }

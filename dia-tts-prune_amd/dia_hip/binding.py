@@ -20,7 +20,7 @@ EPI_SCALE_STORE, EPI_RESID_EMIT, EPI_SWIGLU_EMIT, EPI_CROSSKV = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
 
 EXPORTS = (
-    "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_attn", "dia_enc_kv_prep",
+    "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_gemm_timed", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep",
     "dia_embed_text", "dia_embed_tokens", "dia_sample", "dia_prefetch", "dia_engine_create", "dia_engine_destroy",
     "dia_engine_decode", "dia_engine_step_logits_only", "dia_engine_profile_step", "dia_engine_launches_per_step",
 )
@@ -51,6 +51,7 @@ class AttnArgs(C.Structure):
         ("kc", C.c_void_p), ("vc", C.c_void_p), ("cur", C.c_void_p), ("len", C.c_void_p),
         ("enc_len", C.c_int32), ("_pad0", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("_pad1", C.c_int32),
+        ("scratch", C.c_void_p), ("tickets", C.c_void_p),
     ]
 
 
@@ -99,6 +100,7 @@ class EngineDesc(C.Structure):
         ("x", C.c_void_p), ("planes_x", C.c_void_p), ("planes_a", C.c_void_p), ("planes_h", C.c_void_p),
         ("ssq", C.c_void_p), ("qkv", C.c_void_p), ("qc", C.c_void_p), ("logits", C.c_void_p),
         ("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("text_len", C.c_void_p),
+        ("attn_scratch", C.c_void_p), ("attn_tickets", C.c_void_p),
         ("sample", SampleArgs),
     ]
 
@@ -133,7 +135,9 @@ def lib() -> C.CDLL:
     if L.dia_abi_version() != ABI_VERSION:
         raise DiaHipError(f"ABI mismatch: library {L.dia_abi_version()} vs binding {ABI_VERSION}")
     L.dia_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+    L.dia_gemm_timed.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.POINTER(C.c_float)]
     L.dia_attn.argtypes = [C.POINTER(AttnArgs), C.c_void_p]
+    L.dia_attn_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     L.dia_enc_kv_prep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dia_embed_text.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -173,6 +173,10 @@ class DecodeSession:
         self.k_cross = [z(B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
         self.v_cross = [z(B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
         self.text_len = torch.tensor(self.lens, dtype=torch.int32, device=dev)
+        nsc = max(hb.lib().dia_attn_scratch_floats(self.R, d.kv_heads, self.T),
+                  hb.lib().dia_attn_scratch_floats(B, d.cross_query_heads, self.S))
+        self.attn_scratch = z(max(nsc, 1))
+        self.attn_tickets = z(max(self.R * d.kv_heads, B * d.cross_query_heads), dt=torch.int32)
 
         # token buffer + state machine (state.py:178-208; model.py:736-741)
         from .tokens import delayed_prefill
@@ -271,6 +275,7 @@ class DecodeSession:
         ed.x, ed.planes_x, ed.planes_a, ed.planes_h = hb.ptr(self.x), hb.ptr(self.planes_x), hb.ptr(self.planes_a), hb.ptr(self.planes_h)
         ed.ssq, ed.qkv, ed.qc, ed.logits = hb.ptr(self.ssq), hb.ptr(self.qkv), hb.ptr(self.qc), hb.ptr(self.logits)
         ed.cos_t, ed.sin_t, ed.text_len = hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(self.text_len)
+        ed.attn_scratch, ed.attn_tickets = hb.ptr(self.attn_scratch), hb.ptr(self.attn_tickets)
         ed.sample = self._sample_args()
         self._desc = ed
         hb.check(hb.lib().dia_engine_create(C.byref(ed), C.c_void_p(self.stream.cuda_stream), C.byref(self._engine)),
@@ -317,6 +322,8 @@ class DecodeSession:
                 qkv = torch.zeros(Lp, nq, dtype=torch.float32, device=dev)
                 kc = torch.zeros(e.n_head, Lp, HEAD_DIM, dtype=torch.float32, device=dev)
                 vc = torch.zeros(e.n_head, Lp, HEAD_DIM, dtype=torch.float32, device=dev)
+                esc = torch.zeros(max(1, L.dia_attn_scratch_floats(Lb, e.n_head, Lp)), dtype=torch.float32, device=dev)
+                etk = torch.zeros(Lb * e.n_head, dtype=torch.int32, device=dev)
                 hb.check(L.dia_embed_text(hb.ptr(ids), Lb, hb.ptr(w.enc_emb), E, hb.ptr(w.enc_layers[0]["g_sa"]), hb.ptr(x),
                                           hb.ptr(px), px[0].numel(), ekt, hb.ptr(ssq), Lp, st), "dia_embed_text")
 
@@ -348,6 +355,7 @@ class DecodeSession:
                     a.kc, a.vc, a.enc_len = hb.ptr(kc), hb.ptr(vc), Lb
                     a.cos_t, a.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
                     a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(pa), pa[0].numel(), akt
+                    a.scratch, a.tickets = hb.ptr(esc), hb.ptr(etk)
                     hb.check(L.dia_attn(C.byref(a), st), "dia_attn(enc)")
                     gemm(pa, akt, EL["o"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=EL["g_mlp"], P=px, p_kt=ekt, ssq_out=ssq)
                     gemm(px, ekt, EL["wi"], hb.EPI_SWIGLU_EMIT, ssq_in=ssq, P=ph, p_kt=hkt)
@@ -381,6 +389,33 @@ class DecodeSession:
         buf = (C.c_float * n)()
         hb.check(hb.lib().dia_engine_profile_step(self._engine, buf, n), "dia_engine_profile_step")
         return np.array(buf[:], dtype=np.float64)
+
+    def time_wi_launches(self, reps: int = 5) -> float:
+        """Average seconds per launch of the dominant kernel — the wi_fused GEMV with SwiGLU epilogue —
+        each launch bracketed by dispatch-level HIP start/stop events on the engine's stream
+        (hipExtLaunchKernelGGL), cycling through every layer's matrix (1.2 GB, HBM-cold like in a real
+        step) with exactly the arguments the engine uses.  Outputs go to planes_h, which the next step overwrites."""
+        L = hb.lib()
+        st = C.c_void_p(self.stream.cuda_stream)
+        args = []
+        for DL in self.w.dec_layers:
+            g = hb.GemmArgs()
+            g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(self.planes_x), self.planes_x[0].numel(), self.xkt, self.R
+            g.W, g.KT, g.nstrips, g.epi = hb.ptr(DL["wi"].t), DL["wi"].kt, DL["wi"].ns, hb.EPI_SWIGLU_EMIT
+            g.ssq_in, g.ssq_in_n, g.ssq_ld = hb.ptr(self.ssq), self.D // 16, self.rows_pad
+            g.inv_d, g.eps = 1.0 / self.D, float(self.cfg.model.normalization_layer_epsilon)
+            g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(self.planes_h), self.planes_h[0].numel(), self.hkt
+            args.append(g)
+        for g in args:                                    # warm
+            hb.check(L.dia_gemm(C.byref(g), st), "dia_gemm(wi)")
+        self.stream.synchronize()
+        ms = C.c_float()
+        tot = 0.0
+        for _ in range(reps):
+            for g in args:
+                hb.check(L.dia_gemm_timed(C.byref(g), st, C.byref(ms)), "dia_gemm_timed(wi)")
+                tot += ms.value
+        return tot * 1e-3 / (reps * len(args))
 
     def sync(self):
         self.stream.synchronize()

@@ -90,6 +90,9 @@ typedef struct {
   const float* sin_t;
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
+/* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
+ * kernel's own duration in milliseconds and synchronises on its end */
+int dia_gemm_timed(const dia_gemm_args* a, void* stream, float* ms_out);
 
 /* Single-query attention (decode) and the encoder's bidirectional attention on the same kernel.
  * Replaces RotaryEmbedding.forward (layers.py:135-173), KVCache.update (state.py:99-103),
@@ -118,8 +121,14 @@ typedef struct {
   int64_t p_plane_stride;
   int32_t p_ktiles;
   int32_t _pad1;
+  /* split-key partials: required when more than 128 keys are possible (kv_cap, or enc_len for ENC).
+   * scratch: dia_attn_scratch_floats(pairs_rows, n_kv_heads, kv_cap) floats, pairs_rows = n_rows;
+   * tickets: n_rows*n_kv_heads int32, zero before the first launch (the kernel re-zeroes them). */
+  float* scratch;
+  int32_t* tickets;
 } dia_attn_args;
 int dia_attn(const dia_attn_args* a, void* stream);
+int dia_attn_scratch_floats(int n_rows, int n_kv_heads, int kv_cap);
 
 /* Encoder helper: RoPE(k) and v of all L tokens from the qkv rows into an fp32 [heads][cap][128]
  * scratch "cache" (layers.py:274-279,306-307 for the encoder). */
@@ -217,6 +226,8 @@ typedef struct {
   const float* cos_t;       /* [T+1][64] */
   const float* sin_t;
   const int32_t* text_len;  /* [B] */
+  float* attn_scratch;      /* max over self/cross of dia_attn_scratch_floats(...) floats */
+  int32_t* attn_tickets;    /* max(R*kv_heads, B*cq_heads) int32, zeroed by the caller once */
   dia_sample_args sample;   /* sampler + FSM + embedding parameters */
 } dia_engine_desc;
 

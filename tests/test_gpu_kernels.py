@@ -157,7 +157,7 @@ def attn_ref(q, K, V):
 
 
 @pytest.mark.parametrize("kvd", ["f32", "bf16"])
-@pytest.mark.parametrize("B,cur", [(1, 1), (1, 37), (2, 300), (1, 1025)])
+@pytest.mark.parametrize("B,cur", [(1, 1), (1, 37), (1, 128), (1, 129), (2, 300), (1, 1025), (1, 1280)])
 def test_attn_self(kvd, B, cur):
     d = dev()
     torch.manual_seed(cur)
@@ -178,8 +178,14 @@ def test_attn_self(kvd, B, cur):
     a.kc, a.vc, a.cur = hb.ptr(kc), hb.ptr(vc), hb.ptr(curs)
     a.cos_t, a.sin_t = hb.ptr(cos), hb.ptr(sin)
     a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(P), P[0].numel(), P.shape[2]
-    hb.check(hb.lib().dia_attn(C.byref(a), None), "dia_attn")
+    scr = torch.zeros(hb.lib().dia_attn_scratch_floats(R, KVH, T), device=d)
+    tk = torch.zeros(R * KVH, dtype=torch.int32, device=d)
+    a.scratch, a.tickets = hb.ptr(scr), hb.ptr(tk)
+    for _ in range(2):                                  # second launch: tickets were re-zeroed by the kernel
+        kc.copy_(kc0); vc.copy_(vc0)
+        hb.check(hb.lib().dia_attn(C.byref(a), None), "dia_attn")
     torch.cuda.synchronize()
+    assert (tk == 0).all()
     out = lay.unpack_planes(P, R, QH * 128).double().reshape(R, QH, 128)
 
     def rope(x, pos):
@@ -227,6 +233,9 @@ def test_attn_cross_and_uncond_zero(kvd):
     a.kc, a.vc, a.cur, a.len = hb.ptr(kc), hb.ptr(vc), hb.ptr(cur), hb.ptr(ln)
     a.cos_t, a.sin_t = hb.ptr(cos), hb.ptr(sin)
     a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(P), P[0].numel(), P.shape[2]
+    scr = torch.zeros(hb.lib().dia_attn_scratch_floats(B, H, S), device=d)
+    tk = torch.zeros(B * H, dtype=torch.int32, device=d)
+    a.scratch, a.tickets = hb.ptr(scr), hb.ptr(tk)
     hb.check(hb.lib().dia_attn(C.byref(a), None), "dia_attn")
     torch.cuda.synchronize()
     out = lay.unpack_planes(P, R, H * 128).double().reshape(R, H, 128)
