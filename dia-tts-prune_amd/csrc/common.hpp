@@ -59,6 +59,13 @@ __device__ __forceinline__ void emit_planes8(bf16_raw* P, long plane_stride, int
   *reinterpret_cast<bf16x8*>(P + 2 * plane_stride + off) = lo;
 }
 
+// Workgroup barrier for LDS hand-offs that does NOT drain outstanding global loads: __syncthreads()
+// makes hipcc wait vmcnt(0), which would serialise the weight stream behind every barrier (guide §5
+// 'Pipelining across barriers').  LDS operations are waited for explicitly.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -157,11 +157,11 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
 }
 
 // split-K partials -> LDS -> fixed-order sum -> 16x16 tile(s) in LDS
-template <int MT, int NW>
+template <int MT, int NW, bool RAW = false>
 __device__ __forceinline__ void reduce_to_tile(const f32x4* acc, f32x4* red, float* tile, int tid, int lane, int w) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) red[(w * MT + mt) * 64 + lane] = acc[mt];
-  __syncthreads();
+  if constexpr (RAW) lds_barrier(); else __syncthreads();
   if (tid < MT * 64) {
     const int mt = tid >> 6;
     f32x4 s = red[(0 * MT + mt) * 64 + lane];
@@ -174,7 +174,7 @@ __device__ __forceinline__ void reduce_to_tile(const f32x4* acc, f32x4* red, flo
 #pragma unroll
     for (int r = 0; r < 4; ++r) tile[(mt * 16 + r0 + r) * 17 + col] = s[r];
   }
-  __syncthreads();
+  if constexpr (RAW) lds_barrier(); else __syncthreads();
 }
 
 template <int MT, int NW, int KPW>
@@ -274,6 +274,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
 // M <= RS rows (RS = 2 or 4): the valid rows of all three planes are staged once per workgroup into
 // LDS as [plane][ktile][kq 0..3][row 0..RS-1] x 16 B; lane l of a wave then reads its A fragment for
 // k-tile kt at ((plane*KT + kt)*4 + (l>>4))*RS + min(l&15, RS-1) (rows >= RS alias row RS-1: broadcast).
+#ifdef DIA_DBG_STAMPS
+__device__ long long g_stamps[4096 * 8];
+#define STAMP(i) do { if (tid == 0) g_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 template <int NW, int KPW, int RS, bool MULTI>
 __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -292,9 +299,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
     for (int i = 0; i < KPW; ++i) b[i] = DIA_WLOAD(Wt + (long)i * 64);
   };
 
+  STAMP(0);
   bf16x8 b0[KPW], b1[MULTI ? KPW : 1];
-  load_strip(b0, blockIdx.x);
-  __builtin_amdgcn_sched_barrier(0);
+  constexpr int KT = NW * KPW;             // the dispatcher only picks this kernel when p.KT == NW*KPW
+  constexpr int NT = NW * 64;
 
   const int e_r = (tid >> 1) & 15, half = tid & 1;
   const int m = e_r;
@@ -302,25 +310,64 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
   const bool live = e_thread && m < p.M;
   float xpre[8], gpre[8];
 
-  // ---- stage the compact A (L2-resident, tiny) once: chunk c = ((plane*KT + kt)*4 + kq)*RS + row
-  constexpr int NT = NW * 64;
-  constexpr int CH = 4;                               // chunks in flight per thread per round
-  const int nchunks = DIA_NPLANES * p.KT * 4 * RS;
-  for (int c0 = tid; c0 < nchunks; c0 += NT * CH) {
-    bf16x8 v[CH];
+  // ---- every small, L2-resident operand is requested BEFORE the weight stream, branch-free: vmcnt
+  // retires in order, so anything queued behind 16-32 KiB of HBM loads per wave would stall its first
+  // use (and with it the barrier below) until the whole strip has arrived.
+  // (1) compact A image: chunk c = ((plane*KT + kt)*4 + kq)*RS + row, 16 bytes each
+  constexpr int CH = (3 * KPW * RS + 15) / 16;        // chunks per thread = 3*KT*4*RS / NT
+  constexpr int nchunks = DIA_NPLANES * KT * 4 * RS;
+  bf16x8 v0[CH];
 #pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const int c = min(c0 + u * NT, nchunks - 1);
-      const int row = c % RS, kq = (c / RS) & 3, kt = (c / (4 * RS)) % p.KT, pl = c / (4 * RS * p.KT);
-      v[u] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)kt * 64 + row + 16 * kq) * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < CH; ++u)
-      if (c0 + u * NT < nchunks) As[c0 + u * NT] = v[u];
+  for (int u = 0; u < CH; ++u) {
+    const int c = min(tid + u * NT, nchunks - 1);
+    const int row = c % RS, kq = (c / RS) & 3, kt = (c / (4 * RS)) % KT, pl = c / (4 * RS * KT);
+    v0[u] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)kt * 64 + row + 16 * kq) * 8);
   }
-  // row scales (same rows for every strip) + first strip's residual operands
-  prefetch_epilogue<1, NT>(p, tid, 0, m, blockIdx.x * 16 + half * 8, live, xpre, gpre, inv_s);
-  __syncthreads();
+  // (2) strip sums of squares for the row scale: 8 threads per row, up to 16 strips each per round
+  const bool has_norm = p.ssq_in != nullptr;
+  const int s_row = tid >> 3, s_part = tid & 7;
+  const bool s_thread = tid < 128 && has_norm;
+  float sq[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sq[i] = 0.f;
+  if (s_thread) {        // one exec-masked region, 16 unconditional loads on clamped addresses
+    const float* sp = p.ssq_in + min(s_row, p.M - 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sq[i] = sp[(long)min(s_part + 8 * i, p.ssq_in_n - 1) * p.ssq_ld];
+  }
+  // (3) residual row + next norm weight of the first strip (RESID_EMIT only)
+  const bool resid = p.epi == DIA_EPI_RESID_EMIT;
+  auto load_resid = [&](int strip) {
+    const int n0 = strip * 16 + half * 8;
+    const float* o = p.out + (long)(live ? m : 0) * p.ldo + n0;
+    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+    xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+    xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+    const float4 ga = *reinterpret_cast<const float4*>(p.gnext + n0), gb = *reinterpret_cast<const float4*>(p.gnext + n0 + 4);
+    gpre[0] = ga.x; gpre[1] = ga.y; gpre[2] = ga.z; gpre[3] = ga.w;
+    gpre[4] = gb.x; gpre[5] = gb.y; gpre[6] = gb.z; gpre[7] = gb.w;
+  };
+  if (resid && e_thread) load_resid(blockIdx.x);
+  __builtin_amdgcn_sched_barrier(0);
+  load_strip(b0, blockIdx.x);                       // the HBM stream starts here
+  __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
+#pragma unroll
+  for (int u = 0; u < CH; ++u)
+    if (tid + u * NT < nchunks) As[tid + u * NT] = v0[u];
+  {
+    float s0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s0 += (s_part + 8 * i < p.ssq_in_n && s_row < p.M) ? sq[i] : 0.f;
+    if (s_thread && s_row < p.M)
+      for (int idx = s_part + 128; idx < p.ssq_in_n; idx += 8) s0 += p.ssq_in[(long)idx * p.ssq_ld + s_row];   // D > 2048 only
+    s0 += __shfl_xor(s0, 1, 64);
+    s0 += __shfl_xor(s0, 2, 64);
+    s0 += __shfl_xor(s0, 4, 64);
+    if (tid < 128 && s_part == 0) inv_s[s_row] = has_norm ? rsqrtf(s0 * p.inv_d + p.eps) : 1.0f;
+  }
+  lds_barrier();      // A image + row scales visible; the weight loads stay in flight
+  STAMP(2);
 
   const int arow = min(lane & 15, RS - 1), akq = lane >> 4;
   auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
@@ -331,23 +378,17 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
     for (int i = 0; i < KPW; ++i) {
 #pragma unroll
       for (int pl = 0; pl < DIA_NPLANES; ++pl) {
-        const bf16x8 a = As[((pl * p.KT + kt0 + i) * 4 + akq) * RS + arow];
+        const bf16x8 a = As[((pl * KT + kt0 + i) * 4 + akq) * RS + arow];
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bc[i], acc[0], 0, 0, 0);
       }
     }
-    reduce_to_tile<1, NW>(acc, red, tile, tid, lane, w);
+    STAMP(3);
+    reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
+    STAMP(4);
     if (e_thread) {
       const int n0 = strip * 16 + half * 8;
       run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
-      if (MULTI && next < p.nstrips && p.epi == DIA_EPI_RESID_EMIT && live) {      // residual operands of the next strip
-        const int n1 = next * 16 + half * 8;
-        const float* o = p.out + (long)m * p.ldo + n1;
-        const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
-        xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
-        xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) gpre[j] = p.gnext ? p.gnext[n1 + j] : 1.0f;
-      }
+      if (MULTI && next < p.nstrips && resid) load_resid(next);      // residual operands of the next strip
     }
   };
   if constexpr (MULTI) {
@@ -358,7 +399,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
   } else {
     body(b0, b1, blockIdx.x);
   }
+  STAMP(5);
 }
+
+
 
 template <int MT, int NW, int KPW>
 int launch(const GemmK& k, int mgroups, hipStream_t st) {
@@ -461,6 +505,12 @@ int small_attr() {
 
 }  // namespace
 
+#ifdef DIA_DBG_STAMPS
+extern "C" int dia_dbg_stamps(long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif
+
 // large-LDS attribute of every small-M instantiation, set once outside any graph capture
 int dia_gemm_init() {
   int rc = 0;
@@ -508,7 +558,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   }
   const int mtiles = (a->M + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-  if (a->M <= 4 && a->epi != DIA_EPI_CROSSKV) {
+  if (a->M <= 4 && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext)) {
     const int rs = a->M <= 2 ? 2 : 4;
     if (small_smem(nw, a->KT, rs) <= 150 * 1024) {
       bool handled = false;
