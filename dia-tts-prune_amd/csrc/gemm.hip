@@ -404,6 +404,142 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
 
 
 
+// 5..16 rows (batch 3-8): one m-tile, A fragments held in registers for the workgroup's whole life
+// (each wave owns a fixed K range of KPW k-tiles = 12*KPW VGPRs) and reused for every strip the
+// workgroup walks; weight tiles double-buffered across strips like k_gemv_small.
+template <int NW, int KPW, bool MULTI>
+__global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][64]
+  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * 64);   // [16][17]
+  float* inv_s = tile + 16 * 17;                                           // [16]
+  constexpr int NT = NW * 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kt0 = w * KPW;
+  const int G = gridDim.x;
+  const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + (long)kt0 * 64 + lane;
+  auto load_strip = [&](bf16x8* b, int strip) {
+    const bf16x8* Wt = Wl + (long)strip * p.KT * 64;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) b[i] = DIA_WLOAD(Wt + (long)i * 64);
+  };
+  bf16x8 b0[KPW], b1[MULTI ? KPW : 1];
+
+  const int e_r = (tid >> 1) & 15, half = tid & 1;
+  const int m = e_r;
+  const bool e_thread = tid < 32;
+  const bool live = e_thread && m < p.M;
+  float xpre[8], gpre[8];
+
+  // A fragments (rows >= M alias the last valid row: no extra L2 traffic, results never stored)
+  const int alane = (lane & 48) | min(lane & 15, p.M - 1);
+  bf16x8 a[KPW][DIA_NPLANES];
+#pragma unroll
+  for (int i = 0; i < KPW; ++i)
+#pragma unroll
+    for (int pl = 0; pl < DIA_NPLANES; ++pl)
+      a[i][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)(kt0 + i) * 64 + alane) * 8);
+  // strip sums of squares: 8 threads per row
+  const bool has_norm = p.ssq_in != nullptr;
+  const int s_row = tid >> 3, s_part = tid & 7;
+  const bool s_thread = tid < 128 && has_norm;
+  float sq[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sq[i] = 0.f;
+  if (s_thread) {
+    const float* sp = p.ssq_in + min(s_row, p.M - 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sq[i] = sp[(long)min(s_part + 8 * i, p.ssq_in_n - 1) * p.ssq_ld];
+  }
+  const bool resid = p.epi == DIA_EPI_RESID_EMIT;
+  auto load_resid = [&](int strip) {
+    const int n0 = strip * 16 + half * 8;
+    const float* o = p.out + (long)(live ? m : 0) * p.ldo + n0;
+    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+    xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+    xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+    const float4 ga = *reinterpret_cast<const float4*>(p.gnext + n0), gb = *reinterpret_cast<const float4*>(p.gnext + n0 + 4);
+    gpre[0] = ga.x; gpre[1] = ga.y; gpre[2] = ga.z; gpre[3] = ga.w;
+    gpre[4] = gb.x; gpre[5] = gb.y; gpre[6] = gb.z; gpre[7] = gb.w;
+  };
+  if (resid && e_thread) load_resid(blockIdx.x);
+  __builtin_amdgcn_sched_barrier(0);
+  load_strip(b0, blockIdx.x);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    float s0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s0 += (s_part + 8 * i < p.ssq_in_n && s_row < p.M) ? sq[i] : 0.f;
+    if (s_thread && s_row < p.M)
+      for (int idx = s_part + 128; idx < p.ssq_in_n; idx += 8) s0 += p.ssq_in[(long)idx * p.ssq_ld + s_row];
+    s0 += __shfl_xor(s0, 1, 64);
+    s0 += __shfl_xor(s0, 2, 64);
+    s0 += __shfl_xor(s0, 4, 64);
+    if (tid < 128 && s_part == 0) inv_s[s_row] = has_norm ? rsqrtf(s0 * p.inv_d + p.eps) : 1.0f;
+  }
+
+  auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
+    const int next = strip + G;
+    if constexpr (MULTI) { if (next < p.nstrips) load_strip(bn, next); }
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl)
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], bc[i], acc[0], 0, 0, 0);
+    reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
+    if (e_thread) {
+      const int n0 = strip * 16 + half * 8;
+      run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
+      if (MULTI && next < p.nstrips && resid) load_resid(next);
+    }
+  };
+  if constexpr (MULTI) {
+    for (int strip = blockIdx.x; strip < p.nstrips; strip += 2 * G) {
+      body(b0, b1, strip);
+      if (strip + G < p.nstrips) body(b1, b0, strip + G);
+    }
+  } else {
+    body(b0, b1, blockIdx.x);
+  }
+}
+
+template <int NW, int KPW>
+int launch_g16(const GemmK& k, hipStream_t st) {
+  const size_t smem = sizeof(f32x4) * NW * 64 + sizeof(float) * (16 * 17 + 16);
+  int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
+  if (const char* e = getenv("DIA_DBG_SPW")) spw = atoi(e);
+  if constexpr (!(NW == 16 && KPW >= 4)) {
+    if (spw > 1) {
+      launch_kernel(k_gemm16<NW, KPW, true>, dim3((k.nstrips + spw - 1) / spw), dim3(NW * 64), smem, st, k);
+      return dia_check_launch("k_gemm16");
+    }
+  }
+  launch_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+  return dia_check_launch("k_gemm16");
+}
+
+// returns true when a k_gemm16 instantiation exists for (nw, KT)
+int launch_g16_any(const GemmK& k, int nw, hipStream_t st, bool& handled) {
+  handled = true;
+  const int kpw = (k.KT % nw == 0) ? k.KT / nw : 0;
+  if (nw == 16) {
+    if (kpw == 1) return launch_g16<16, 1>(k, st);
+    if (kpw == 2) return launch_g16<16, 2>(k, st);
+    if (kpw == 4) return launch_g16<16, 4>(k, st);
+  } else if (nw == 8) {
+    if (kpw == 2) return launch_g16<8, 2>(k, st);
+    if (kpw == 4) return launch_g16<8, 4>(k, st);
+    if (kpw == 8) return launch_g16<8, 8>(k, st);
+  } else if (nw == 4) {
+    if (kpw == 4) return launch_g16<4, 4>(k, st);
+    if (kpw == 8) return launch_g16<4, 8>(k, st);
+  }
+  handled = false;
+  return DIA_OK;
+}
+
 template <int MT, int NW, int KPW>
 int launch(const GemmK& k, int mgroups, hipStream_t st) {
   size_t smem = sizeof(f32x4) * NW * MT * 64 + sizeof(float) * (MT * 16 * 17 + MT * 16);
@@ -563,6 +699,17 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
     if (small_smem(nw, a->KT, rs) <= 150 * 1024) {
       bool handled = false;
       int rc = (rs == 2) ? launch_small_rs<2>(k, nw, st, handled) : launch_small_rs<4>(k, nw, st, handled);
+      if (handled) return rc;
+    }
+  }
+  if (mtiles == 1 && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext)) {
+    // registers hold the A fragments: 12*KPW VGPRs, so only short per-wave K ranges qualify
+    int nw16 = a->nw ? a->nw : ((a->KT % 16 == 0 && a->KT / 16 <= 4) ? 16 : ((a->KT % 8 == 0 && a->KT / 8 <= 8) ? 8 : 0));
+    // the persistent multi-strip form double-buffers the weight tiles: 8 waves x 8 k-tiles fit, 16 x 4 spill
+    if (!a->nw && a->nstrips >= 1024 && a->KT % 8 == 0 && a->KT / 8 <= 8) nw16 = 8;
+    if (nw16) {
+      bool handled = false;
+      int rc = launch_g16_any(k, nw16, st, handled);
       if (handled) return rc;
     }
   }
