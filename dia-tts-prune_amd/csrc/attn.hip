@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -36,6 +37,7 @@ struct AttnK {
   const float* cos_t; const float* sin_t;
   bf16_raw* P; long p_plane_stride; int p_ktiles;
   float* scratch; int* tickets; int max_chunks;
+  const int* head_map;
 };
 
 template <typename KVT, int G>
@@ -43,7 +45,8 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
   __shared__ __attribute__((aligned(16))) float q_s[G * HD];
   __shared__ float sc[G * CHUNK];
   __shared__ float part[(NT / 64) * G * HD];
-  __shared__ float m_s[8], l_s[8];
+  __shared__ float m_s[8], l_s[8], alpha_s[8];
+  __shared__ float knew_s[HD], vnew_s[HD];
   __shared__ int last_s;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -63,11 +66,34 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
     qrow = blockIdx.y; kvrow = 0; pos = qrow; nkeys = p.enc_len;
     head_row = qrow;
   }
-  const int nchunks = max(1, (nkeys + CHUNK - 1) / CHUNK);
-  if (chunk >= nchunks) return;                       // uniform: nothing to do for this chunk yet
-  const int k0 = chunk * CHUNK, k1 = min(nkeys, k0 + CHUNK);
+  // The pair's keys are cut into 128-key blocks; this workgroup takes blocks chunk, chunk+NZ, ... (NZ =
+  // gridDim.z is static for the graph) and carries a running softmax across them.
+  const int NZ = gridDim.z;
+  const int nblocks = max(1, (nkeys + CHUNK - 1) / CHUNK);
+  if (chunk >= nblocks) return;                       // uniform: nothing to do for this workgroup yet
+  if (p.head_map) {                                   // every query head of this kv head pruned: no work
+    bool any_live = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) any_live |= p.head_map[kvh * G + g] >= 0;
+    if (!any_live && !(p.mode == DIA_ATTN_SELF)) return;      // (self: the k/v append below must still happen)
+  }
+  const int nchunks = min(NZ, nblocks);               // workgroups that publish a partial for this pair
 
-  // ---- prologue: RoPE(q); the chunk that owns the new slot also ropes k and appends k, v ---------
+  KVT* Kc = reinterpret_cast<KVT*>(p.kc) + ((long)kvrow * p.n_kv_heads + kvh) * p.kv_cap * HD;
+  KVT* Vc = reinterpret_cast<KVT*>(p.vc) + ((long)kvrow * p.n_kv_heads + kvh) * p.kv_cap * HD;
+  const int grp = tid >> 4, sub = tid & 15;
+  float kv[U][8], vv[U][8];
+  auto load_block = [&](int blk) {     // K and V of one block: 4 keys per lane group, all loads in flight
+    const int b0 = blk * CHUNK, blast = max(min(nkeys, b0 + CHUNK) - 1, b0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Kc + (long)min(b0 + grp + u * NGRP, blast) * HD + sub * 8, kv[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Vc + (long)min(b0 + grp + u * NGRP, blast) * HD + sub * 8, vv[u]);
+  };
+  // K and V do not depend on q: request the first block before the prologue so the latencies overlap
+  load_block(chunk);
+
+  // ---- prologue: RoPE(q); the workgroup that owns the new slot also ropes k and appends k, v -------
   const float* qr = p.q + (long)qrow * p.ldq;
   for (int t = tid; t < G * 64; t += NT) {
     const int g = t >> 6, d = t & 63;
@@ -77,37 +103,52 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
     q_s[g * HD + d] = x1 * c - x2 * s;
     q_s[g * HD + d + 64] = x1 * s + x2 * c;
   }
-  KVT* Kc = reinterpret_cast<KVT*>(p.kc) + ((long)kvrow * p.n_kv_heads + kvh) * p.kv_cap * HD;
-  KVT* Vc = reinterpret_cast<KVT*>(p.vc) + ((long)kvrow * p.n_kv_heads + kvh) * p.kv_cap * HD;
-  if (p.mode == DIA_ATTN_SELF && slot >= k0 && slot < k1 && tid >= NT - 64) {
+  const int slot_blk = slot >= 0 ? slot / CHUNK : -1;
+  const bool owns_slot = p.mode == DIA_ATTN_SELF && slot_blk >= 0 && (slot_blk % NZ) == chunk;
+  if (owns_slot && tid >= NT - 64) {
     const int d = tid - (NT - 64);
     const float* kh = qr + p.k_off + kvh * HD;
     const float* vh = qr + p.v_off + kvh * HD;
     const float x1 = kh[d], x2 = kh[d + 64];
     const float c = p.cos_t[(long)pos * 64 + d], s = p.sin_t[(long)pos * 64 + d];
-    KVElem<KVT>::store(Kc + (long)slot * HD + d, x1 * c - x2 * s);
-    KVElem<KVT>::store(Kc + (long)slot * HD + d + 64, x1 * s + x2 * c);
-    KVElem<KVT>::store(Vc + (long)slot * HD + d, vh[d]);
-    KVElem<KVT>::store(Vc + (long)slot * HD + d + 64, vh[d + 64]);
+    const float k1v = KVElem<KVT>::round(x1 * c - x2 * s), k2v = KVElem<KVT>::round(x1 * s + x2 * c);
+    const float v1v = KVElem<KVT>::round(vh[d]), v2v = KVElem<KVT>::round(vh[d + 64]);
+    knew_s[d] = k1v; knew_s[d + 64] = k2v; vnew_s[d] = v1v; vnew_s[d + 64] = v2v;
+    KVElem<KVT>::store(Kc + (long)slot * HD + d, k1v);
+    KVElem<KVT>::store(Kc + (long)slot * HD + d + 64, k2v);
+    KVElem<KVT>::store(Vc + (long)slot * HD + d, v1v);
+    KVElem<KVT>::store(Vc + (long)slot * HD + d + 64, v2v);
   }
-  __syncthreads();     // orders the append before this workgroup's reads of that slot
+  if (tid < 8) { m_s[tid] = -INFINITY; l_s[tid] = 0.f; }
+  __syncthreads();
 
-  // ---- scores: lane group grp handles keys k0 + grp + u*NGRP --------------------------------------
-  const int grp = tid >> 4, sub = tid & 15;
   float qreg[G][8];
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int j = 0; j < 8; ++j) qreg[g][j] = q_s[g * HD + sub * 8 + j];
   const float scale = 0.08838834764831845f;   // 1/sqrt(128)
-  const int klast = max(k1 - 1, k0);
-  {
-    float kv[U][8];
+  float acc[G][8];
 #pragma unroll
-    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Kc + (long)min(k0 + grp + u * NGRP, klast) * HD + sub * 8, kv[u]);
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+
+  for (int blk = chunk; blk < nblocks; blk += NZ) {
+    const int k0 = blk * CHUNK, k1 = min(nkeys, k0 + CHUNK);
+    if (blk != chunk) load_block(blk);
+    if (owns_slot && blk == slot_blk) {     // loads of the slot written this step are stale: take the LDS copy
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (k0 + grp + u * NGRP == slot) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { kv[u][j] = knew_s[sub * 8 + j]; vv[u][j] = vnew_s[sub * 8 + j]; }
+        }
+    }
+    // scores of the block
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int kl = grp + u * NGRP;             // key index inside the chunk
+      const int kl = grp + u * NGRP;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         float s = 0.f;
@@ -120,40 +161,42 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
         if (sub == 0) sc[g * CHUNK + kl] = (k0 + kl < k1) ? s * scale : -INFINITY;
       }
     }
-  }
-  // V loads are independent of the softmax: request them now
-  float vv[U][8];
-#pragma unroll
-  for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Vc + (long)min(k0 + grp + u * NGRP, klast) * HD + sub * 8, vv[u]);
-  __syncthreads();
-
-  // ---- chunk-local softmax numerators (wave g handles query head g) --------------------------------
-  if (w < G) {
-    float* s = sc + w * CHUNK;
-    const float a = s[lane], b = s[lane + 64];
-    const float m = wave_max(fmaxf(a, b));
-    const float ea = (nkeys > 0) ? expf(a - m) : 0.f, eb = (nkeys > 0) ? expf(b - m) : 0.f;   // exp(-inf) = 0 for padding keys
-    s[lane] = ea; s[lane + 64] = eb;
-    const float l = wave_sum(ea + eb);
-    if (lane == 0) { m_s[w] = m; l_s[w] = l; }
-  }
-  __syncthreads();
-
-  // ---- P.V --------------------------------------------------------------------------------------
-  float acc[G][8];
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int kl = grp + u * NGRP;
+    __syncthreads();
+    // running softmax (wave g handles query head g): new max, rescale factor for what is accumulated
+    if (w < G) {
+      float* s = sc + w * CHUNK;
+      const float a = s[lane], b = s[lane + 64];
+      const float mold = m_s[w];
+      const float mnew = fmaxf(mold, wave_max(fmaxf(a, b)));
+      const bool any = nkeys > 0;
+      const float ea = any ? expf(a - mnew) : 0.f, eb = any ? expf(b - mnew) : 0.f;   // exp(-inf) = 0 for padding keys
+      s[lane] = ea; s[lane + 64] = eb;
+      const float lb = wave_sum(ea + eb);
+      if (lane == 0) {
+        const float alpha = (mold == -INFINITY) ? 0.f : expf(mold - mnew);
+        alpha_s[w] = alpha;
+        l_s[w] = l_s[w] * alpha + lb;
+        m_s[w] = mnew;
+      }
+    }
+    __syncthreads();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const float pk = sc[g * CHUNK + kl];
+      const float al = alpha_s[g];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[g][j] += pk * vv[u][j];
+      for (int j = 0; j < 8; ++j) acc[g][j] *= al;
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kl = grp + u * NGRP;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float pk = sc[g * CHUNK + kl];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] += pk * vv[u][j];
+      }
+    }
+    if (blk + NZ < nblocks) __syncthreads();      // sc / alpha_s are rewritten by the next block
   }
 #pragma unroll
   for (int g = 0; g < G; ++g)
@@ -214,19 +257,33 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
     if (!last_s) return;
     if (o_thread) {
       const float* base = p.scratch + pair * p.max_chunks * SLAB;
+      constexpr int MAXC = 24;               // 3072 keys / 128
+      float mc[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) mc[c] = base[(long)min(c, nchunks - 1) * SLAB + og];   // independent loads
       float mm = -INFINITY;
-      for (int c = 0; c < nchunks; ++c) mm = fmaxf(mm, base[(long)c * SLAB + og]);
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) mm = fmaxf(mm, mc[c]);
+      for (int c = MAXC; c < nchunks; ++c) mm = fmaxf(mm, base[(long)c * SLAB + og]);        // capacity > 3072 only
       float L2 = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = 0.f;
-      for (int c = 0; c < nchunks; ++c) {                       // chunk order: deterministic
-        const float* sl = base + (long)c * SLAB;
-        const float f = expf(sl[og] - mm);
-        L2 += sl[8 + og] * f;
-        const float4 a = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0);
-        const float4 b = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0 + 4);
-        o[0] += a.x * f; o[1] += a.y * f; o[2] += a.z * f; o[3] += a.w * f;
-        o[4] += b.x * f; o[5] += b.y * f; o[6] += b.z * f; o[7] += b.w * f;
+      for (int c0 = 0; c0 < nchunks; c0 += 8) {                     // chunk order: deterministic
+        float lc[8], fm[8]; float4 oa[8], ob[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float* sl = base + (long)min(c0 + u, nchunks - 1) * SLAB;
+          fm[u] = sl[og]; lc[u] = sl[8 + og];
+          oa[u] = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0);
+          ob[u] = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float f = (c0 + u < nchunks) ? expf(fm[u] - mm) : 0.f;
+          L2 += lc[u] * f;
+          o[0] += oa[u].x * f; o[1] += oa[u].y * f; o[2] += oa[u].z * f; o[3] += oa[u].w * f;
+          o[4] += ob[u].x * f; o[5] += ob[u].y * f; o[6] += ob[u].z * f; o[7] += ob[u].w * f;
+        }
       }
       Lsum = L2;
     }
@@ -236,9 +293,10 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
     const float invl = Lsum > 0.f ? 1.0f / Lsum : 0.f;   // no keys (empty text) -> 0, like a fully masked row
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] *= invl;
-    const int col = (kvh * G + og) * HD + od0;
-    emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, qrow, col, o);
-    if (p.mode == DIA_ATTN_CROSS) {
+    const int hpos = p.head_map ? p.head_map[kvh * G + og] : kvh * G + og;   // compacted o_proj input
+    const int col = hpos * HD + od0;
+    if (hpos >= 0) emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, qrow, col, o);
+    if (p.mode == DIA_ATTN_CROSS && hpos >= 0) {
       // the uncond row's cross-attention mask is all False -> SDPA returns 0
       const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, qrow - 1, col, z);
@@ -283,7 +341,12 @@ extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
   if (a->n_rows <= 0 || a->n_kv_heads <= 0) return dia_fail(DIA_E_ARG, "dia_attn: empty problem");
   if (a->p_plane_stride % 8 != 0) return dia_fail(DIA_E_ARG, "dia_attn: plane stride must be a multiple of 8");
   const int cap_keys = a->mode == DIA_ATTN_ENC ? a->enc_len : a->kv_cap;
-  const int max_chunks = (cap_keys + CHUNK - 1) / CHUNK;
+  const int cap_chunks = (cap_keys + CHUNK - 1) / CHUNK;
+  // key-split factor: enough workgroups to cover the 256 CUs once, never more than one per 128-key block
+  int max_chunks = (256 + a->n_rows * a->n_kv_heads - 1) / (a->n_rows * a->n_kv_heads);
+  if (const char* e = getenv("DIA_DBG_NZ")) { if (atoi(e) > 0) max_chunks = atoi(e); }
+  if (max_chunks > cap_chunks) max_chunks = cap_chunks;
+  if (max_chunks < 1) max_chunks = 1;
   if (max_chunks > 1 && (!a->scratch || !a->tickets)) return dia_fail(DIA_E_ARG, "dia_attn: more than 128 keys possible: scratch and tickets are required");
   AttnK k;
   k.mode = a->mode; k.n_kv_heads = a->n_kv_heads; k.n_rows = a->n_rows; k.kv_cap = a->kv_cap;
@@ -291,6 +354,7 @@ extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
   k.kc = a->kc; k.vc = a->vc; k.cur = a->cur; k.len = a->len; k.enc_len = a->enc_len;
   k.cos_t = a->cos_t; k.sin_t = a->sin_t;
   k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles;
+  k.head_map = a->head_map;
   k.scratch = a->scratch; k.tickets = a->tickets; k.max_chunks = (a->kv_cap + CHUNK - 1) / CHUNK;
   if ((a->n_kv_heads * a->group * 128 + 31) / 32 > a->p_ktiles) return dia_fail(DIA_E_ARG, "dia_attn: output planes too narrow");
   hipStream_t st = (hipStream_t)stream;

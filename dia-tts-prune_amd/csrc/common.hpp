@@ -66,6 +66,23 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// compacted consumers: column n0+j goes to plane position cmap[n0+j] (2-byte stores), or nowhere
+__device__ __forceinline__ void emit_planes8_mapped(bf16_raw* P, long plane_stride, int ktiles, int m, int n0,
+                                                    const float* v, const int* cmap) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cmap[n0 + j];
+    if (c >= 0) {
+      __bf16 a, b, d;
+      split3(v[j], a, b, d);
+      const long off = plane_frag_off(m, c & ~7, ktiles) + (c & 7);
+      P[off] = *reinterpret_cast<bf16_raw*>(&a);
+      P[plane_stride + off] = *reinterpret_cast<bf16_raw*>(&b);
+      P[2 * plane_stride + off] = *reinterpret_cast<bf16_raw*>(&d);
+    }
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

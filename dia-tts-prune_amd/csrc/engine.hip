@@ -52,13 +52,14 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
     g.W = L.w_qkv; g.KT = L.kt_qkv; g.nstrips = L.ns_qkv; g.epi = DIA_EPI_SCALE_STORE;
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
-    g.out = d.qkv; g.ldo = nqkv;
+    g.out = d.qkv; g.ldo = nqkv; g.strip_map = L.smap_qkv;
     if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     dia_attn_args a = {};
     a.mode = DIA_ATTN_SELF; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.kv_heads; a.group = d.q_heads / d.kv_heads;
     a.n_rows = R; a.kv_cap = d.T; a.q = d.qkv; a.ldq = nqkv; a.q_off = 0; a.k_off = d.q_heads * 128;
     a.v_off = (d.q_heads + d.kv_heads) * 128; a.kc = L.k_self; a.vc = L.v_self; a.cur = d.sample.cur;
+    a.head_map = L.hmap_self;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
     a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
     if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
@@ -67,7 +68,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g = {};
     g.A = d.planes_a; g.a_plane_stride = as; g.a_ktiles = akt; g.M = R;
     g.W = L.w_o; g.KT = L.kt_o; g.nstrips = L.ns_o; g.epi = DIA_EPI_RESID_EMIT;
-    g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_ca;
+    g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_ca; g.cmap = L.cmap_ca;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
@@ -76,13 +77,13 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
     g.W = L.w_cq; g.KT = L.kt_cq; g.nstrips = L.ns_cq; g.epi = DIA_EPI_SCALE_STORE;
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
-    g.out = d.qc; g.ldo = d.cq_heads * 128;
+    g.out = d.qc; g.ldo = d.cq_heads * 128; g.strip_map = L.smap_cq;
     if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     a = {};
     a.mode = DIA_ATTN_CROSS; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.cq_heads; a.group = 1;
     a.n_rows = d.B; a.kv_cap = d.S; a.q = d.qc; a.ldq = d.cq_heads * 128; a.q_off = 0;
-    a.kc = L.k_cross; a.vc = L.v_cross; a.cur = d.sample.cur; a.len = d.text_len;
+    a.kc = L.k_cross; a.vc = L.v_cross; a.cur = d.sample.cur; a.len = d.text_len; a.head_map = L.hmap_cross;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
     a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
     if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
@@ -90,7 +91,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g = {};
     g.A = d.planes_a; g.a_plane_stride = as; g.a_ktiles = akt; g.M = R;
     g.W = L.w_co; g.KT = L.kt_co; g.nstrips = L.ns_co; g.epi = DIA_EPI_RESID_EMIT;
-    g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_mlp;
+    g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_mlp; g.cmap = L.cmap_mlp;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
@@ -107,6 +108,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.W = L.w_wo; g.KT = L.kt_wo; g.nstrips = L.ns_wo; g.epi = DIA_EPI_RESID_EMIT;
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D;
     g.gnext = (l + 1 < d.n_layer) ? e->layers[l + 1].g_sa : d.g_final;
+    g.cmap = L.cmap_next;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
   }

@@ -57,6 +57,7 @@ struct GemmK {
   void* kc; void* vc; int kv_dtype; int kv_heads; int kv_cap; int kv_batch_index;
   const float* cos_t; const float* sin_t;
   int spw;
+  const int* cmap; const int* strip_map;
 };
 
 __device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v) {
@@ -100,8 +101,10 @@ __device__ __forceinline__ void prefetch_epilogue(const GemmK& p, int tid, int m
 // One thread = one row x 8 consecutive columns of the finished 16x16 tile.
 __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, float inv, int m, int n0, int half,
                                              int strip, bool live, const float* xpre, const float* gpre) {
+  // (n0 and strip are by-value copies: the compaction maps below redirect them)
   if (p.epi == DIA_EPI_SCALE_STORE) {
     if (!live) return;
+    if (p.strip_map) n0 = p.strip_map[strip] * 16 + half * 8;     // compacted output: whole heads dropped
     float4 a = {trow[half * 8 + 0] * inv, trow[half * 8 + 1] * inv, trow[half * 8 + 2] * inv, trow[half * 8 + 3] * inv};
     float4 b = {trow[half * 8 + 4] * inv, trow[half * 8 + 5] * inv, trow[half * 8 + 6] * inv, trow[half * 8 + 7] * inv};
     float* o = p.out + (long)m * p.ldo + n0;
@@ -120,7 +123,8 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
       for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = mul_rn(v[j], gpre[j]);
-      emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, m, n0, v);
+      if (p.cmap) emit_planes8_mapped(p.P, p.p_plane_stride, p.p_ktiles, m, n0, v, p.cmap);
+      else emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, m, n0, v);
     }
     float other = __shfl_xor(ss, 1, 64);
     if (half == 0 && live) p.ssq_out[(long)strip * p.ssq_ld + m] = ss + other;
@@ -135,6 +139,7 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
     emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, m, strip * 8, v);
   } else {  // DIA_EPI_CROSSKV: strips [0, heads*8) hold K as RoPE pairs (d, d+64), the rest hold V
     if (!live) return;
+    if (p.strip_map) strip = p.strip_map[strip];                  // compacted cross K/V: original strip index
     const int nk = p.kv_heads * 8;
     if (strip < nk) {
       const int head = strip >> 3, i0 = (strip & 7) * 8 + half * 4;
@@ -661,13 +666,13 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   if (a->M <= 0 || a->KT <= 0 || a->nstrips <= 0) return dia_fail(DIA_E_ARG, "dia_gemm: empty problem");
   if (a->KT > a->a_ktiles) return dia_fail(DIA_E_ARG, "dia_gemm: weight K exceeds the plane layout's K");
   if (a->a_plane_stride % 8 != 0 || a->p_plane_stride % 8 != 0) return dia_fail(DIA_E_ARG, "dia_gemm: plane stride must be a multiple of 8");
-  if ((a->epi == DIA_EPI_SCALE_STORE || a->epi == DIA_EPI_RESID_EMIT) && (!a->out || a->ldo < a->nstrips * 16 || a->ldo % 4 != 0))
+  if ((a->epi == DIA_EPI_SCALE_STORE || a->epi == DIA_EPI_RESID_EMIT) && (!a->out || (!a->strip_map && a->ldo < a->nstrips * 16) || a->ldo % 4 != 0))
     return dia_fail(DIA_E_ARG, "dia_gemm: output leading dimension too small");
   if ((a->epi == DIA_EPI_RESID_EMIT) && (!a->P || !a->ssq_out || a->p_ktiles * 32 < a->nstrips * 16))
     return dia_fail(DIA_E_ARG, "dia_gemm: RESID_EMIT needs planes and ssq_out covering N");
   if ((a->epi == DIA_EPI_SWIGLU_EMIT) && (!a->P || a->p_ktiles * 32 < a->nstrips * 8))
     return dia_fail(DIA_E_ARG, "dia_gemm: SWIGLU_EMIT needs planes covering N/2");
-  if (a->epi == DIA_EPI_CROSSKV && (!a->kc || !a->vc || !a->cos_t || !a->sin_t || a->nstrips != a->kv_heads * 16 || a->M > a->kv_cap))
+  if (a->epi == DIA_EPI_CROSSKV && (!a->kc || !a->vc || !a->cos_t || !a->sin_t || (!a->strip_map && a->nstrips != a->kv_heads * 16) || a->M > a->kv_cap))
     return dia_fail(DIA_E_ARG, "dia_gemm: CROSSKV shape mismatch");
   if (a->epi < 0 || a->epi > DIA_EPI_CROSSKV) return dia_fail(DIA_E_ARG, "dia_gemm: unknown epilogue");
   if (a->ssq_in && a->ssq_ld < ((a->M + 15) / 16) * 16) return dia_fail(DIA_E_ARG, "dia_gemm: ssq_ld smaller than padded rows");
@@ -680,6 +685,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles; k.ssq_out = a->ssq_out;
   k.kc = a->kc; k.vc = a->vc; k.kv_dtype = a->kv_dtype; k.kv_heads = a->kv_heads; k.kv_cap = a->kv_cap;
   k.kv_batch_index = a->kv_batch_index; k.cos_t = a->cos_t; k.sin_t = a->sin_t; k.spw = a->spw;
+  k.cmap = a->cmap; k.strip_map = a->strip_map;
 
   int nw = a->nw;
   if (nw == 0) {

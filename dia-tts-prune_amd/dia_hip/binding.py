@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("ssq_out", C.c_void_p),
         ("kc", C.c_void_p), ("vc", C.c_void_p), ("kv_dtype", C.c_int32), ("kv_heads", C.c_int32), ("kv_cap", C.c_int32),
         ("kv_batch_index", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
+        ("cmap", C.c_void_p), ("strip_map", C.c_void_p),
     ]
 
 
@@ -51,7 +52,7 @@ class AttnArgs(C.Structure):
         ("kc", C.c_void_p), ("vc", C.c_void_p), ("cur", C.c_void_p), ("len", C.c_void_p),
         ("enc_len", C.c_int32), ("_pad0", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("_pad1", C.c_int32),
-        ("scratch", C.c_void_p), ("tickets", C.c_void_p),
+        ("scratch", C.c_void_p), ("tickets", C.c_void_p), ("head_map", C.c_void_p),
     ]
 
 
@@ -61,6 +62,7 @@ class EmbedArgs(C.Structure):
         ("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("V", C.c_int32), ("D", C.c_int32), ("_pad0", C.c_int32),
         ("emb", C.c_void_p), ("g", C.c_void_p), ("x", C.c_void_p), ("P", C.c_void_p),
         ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("ssq_ld", C.c_int32), ("ssq", C.c_void_p),
+        ("cmap", C.c_void_p),
     ]
 
 
@@ -86,6 +88,8 @@ class DecLayer(C.Structure):
         ("kt_qkv", C.c_int32), ("ns_qkv", C.c_int32), ("kt_o", C.c_int32), ("ns_o", C.c_int32),
         ("kt_cq", C.c_int32), ("ns_cq", C.c_int32), ("kt_co", C.c_int32), ("ns_co", C.c_int32),
         ("kt_wi", C.c_int32), ("ns_wi", C.c_int32), ("kt_wo", C.c_int32), ("ns_wo", C.c_int32),
+        ("cmap_ca", C.c_void_p), ("cmap_mlp", C.c_void_p), ("cmap_next", C.c_void_p),
+        ("smap_qkv", C.c_void_p), ("smap_cq", C.c_void_p), ("hmap_self", C.c_void_p), ("hmap_cross", C.c_void_p),
     ]
 
 

@@ -1,0 +1,103 @@
+"""Structured-pruned checkpoint -> physically smaller tensors (BASELINE config 4).
+
+``offline_prune.py --prune-mode structured --prune-dim 0`` (reference offline_prune.py:82-156 ->
+dia/pruning_utils.py:64-151) leaves a same-shape checkpoint in which whole dim-0 slices of every
+DenseGeneral kernel are zero: input features of q/k/v/wi_fused/wo/logits, and whole heads of
+o_proj.  The checkpoint carries no mask (``prune.remove``, pruning_utils.py:145), so the structure is
+recovered from the zeros.  Compaction then
+
+* drops the zero rows of every matrix (K-compaction): the consumer's activations are emitted by their
+  producer directly in the compacted order (``cmap``), so nothing is gathered at run time;
+* propagates dead structure: heads zeroed in ``o_proj`` make the matching q columns (and a kv head
+  whose every query head is gone) unnecessary, hidden units zeroed in ``wo`` make the matching gate/up
+  columns of ``wi_fused`` unnecessary (N-compaction, ``strip_map`` / ``head_map``).
+
+A zero row contributes exactly 0.0 to an fp32 dot product, so results equal the zero-streaming path up
+to summation order.  q, k and v share one activation plane set, so their K-compaction uses the union
+of the three keep sets (rows zero in only one of them are stored as zeros).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+
+def nonzero_rows(w2d: torch.Tensor) -> torch.Tensor:
+    """bool [K]: rows of a [K, N] matrix that are not identically zero."""
+    return (w2d != 0).any(dim=1)
+
+
+def _cmap(keep: torch.Tensor) -> torch.Tensor:
+    """bool [D] -> int32 [D]: compact position of every kept column, -1 for dropped ones."""
+    idx = torch.cumsum(keep.to(torch.int32), dim=0) - 1
+    return torch.where(keep, idx, torch.full_like(idx, -1)).to(torch.int32)
+
+
+@dataclass
+class LayerPlan:
+    keep_qkv: torch.Tensor            # bool [D]  union of q/k/v input rows
+    keep_cq: torch.Tensor             # bool [D]
+    keep_wi: torch.Tensor             # bool [D]
+    live_q_heads: torch.Tensor        # bool [q_heads]      (from self o_proj)
+    live_kv_heads: torch.Tensor       # bool [kv_heads]
+    live_c_heads: torch.Tensor        # bool [cq_heads]     (from cross o_proj)
+    live_hidden: torch.Tensor         # bool [F]            (from wo)
+    keep_ckv: torch.Tensor            # bool [E] union of cross k/v input rows (prefill)
+
+
+def plan_decoder_layer(sd: Dict[str, torch.Tensor], prefix: str, q_heads: int, kv_heads: int, cq_heads: int) -> LayerPlan:
+    g = lambda n: sd[prefix + n]
+    D = g("self_attention.q_proj.weight").shape[0]
+    rows = lambda n: nonzero_rows(g(n).reshape(g(n).shape[0], -1))
+    keep_qkv = rows("self_attention.q_proj.weight") | rows("self_attention.k_proj.weight") | rows("self_attention.v_proj.weight")
+    live_q = nonzero_rows(g("self_attention.o_proj.weight").reshape(q_heads, -1))
+    grp = q_heads // kv_heads
+    live_kv = live_q.reshape(kv_heads, grp).any(dim=1)
+    live_c = nonzero_rows(g("cross_attention.o_proj.weight").reshape(cq_heads, -1))
+    keep_ckv = rows("cross_attention.k_proj.weight") | rows("cross_attention.v_proj.weight")
+    return LayerPlan(keep_qkv, rows("cross_attention.q_proj.weight"), rows("mlp.wi_fused.weight"),
+                     live_q, live_kv, live_c, rows("mlp.wo.weight"), keep_ckv)
+
+
+def is_pruned(plan: LayerPlan) -> bool:
+    return not bool(plan.keep_qkv.all() and plan.keep_cq.all() and plan.keep_wi.all() and plan.live_q_heads.all()
+                    and plan.live_c_heads.all() and plan.live_hidden.all())
+
+
+def head_map(live: torch.Tensor) -> torch.Tensor:
+    return _cmap(live)
+
+
+def strips_of_heads(live_heads: torch.Tensor, head_offset_cols: int = 0) -> List[int]:
+    """original 16-column strip indices covered by the live 128-wide heads, in order"""
+    out: List[int] = []
+    for h in torch.nonzero(live_heads).flatten().tolist():
+        base = (head_offset_cols + h * 128) // 16
+        out.extend(range(base, base + 8))
+    return out
+
+
+def pad_hidden_keep(live_hidden: torch.Tensor) -> torch.Tensor:
+    """indices of the live hidden units (int64), their count padded up to a multiple of 8 with -1"""
+    idx = torch.nonzero(live_hidden).flatten()
+    pad = (-idx.numel()) % 8
+    if pad:
+        idx = torch.cat([idx, torch.full((pad,), -1, dtype=idx.dtype, device=idx.device)])
+    return idx
+
+
+def take_rows(w2d: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:
+    return w2d[keep]
+
+
+def take_cols_idx(w2d: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """columns by index; index -1 -> a zero column"""
+    safe = idx.clamp(min=0)
+    out = w2d[:, safe]
+    if (idx < 0).any():
+        out = out.clone()
+        out[:, idx < 0] = 0
+    return out

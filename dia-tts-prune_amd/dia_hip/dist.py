@@ -26,7 +26,11 @@ def weight_tensors(w) -> List[torch.Tensor]:
     out += [w.enc_norm, w.dec_emb]
     for L in w.dec_layers:
         out += [L["g_sa"], L["g_ca"], L["g_mlp"]] + [L[k].t for k in ("qkv", "o", "cq", "co", "ckv", "wi", "wo")]
+        out += [L[k] for k in ("cmap_ca", "cmap_mlp", "cmap_next", "smap_qkv", "smap_cq", "smap_ckv", "hmap_self", "hmap_cross")
+                if L[k] is not None]
     out += [w.dec_norm, w.logits.t, w.cos_t, w.sin_t]
+    if w.cmap_first is not None:
+        out.append(w.cmap_first)
     return out
 
 
@@ -44,6 +48,9 @@ def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, group=None)
 
 
 def broadcast_weights(w, src: int = 0, group=None) -> int:
+    if getattr(w, "compacted", False):
+        raise ValueError("compacted (structured-pruned) weights have checkpoint-dependent shapes: "
+                         "load the checkpoint on every rank instead of broadcasting")
     return broadcast_tensors(weight_tensors(w), src=src, group=group)
 
 

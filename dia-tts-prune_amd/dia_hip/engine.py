@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import binding as hb
+from . import compact as cpt
 from . import layout as lay
 from .config import DiaConfig
 
@@ -46,7 +47,9 @@ class TiledW:
 class DeviceWeights:
     """Checkpoint -> kernel layouts, resident in HBM (bf16 tiles; norms / embeddings fp32)."""
 
-    def __init__(self, cfg: DiaConfig, sd: Dict[str, torch.Tensor], device: torch.device):
+    def __init__(self, cfg: DiaConfig, sd: Dict[str, torch.Tensor], device: torch.device, compact: str = "auto"):
+        """compact: "auto" = drop structure that a structured-pruned checkpoint zeroed (decoder only),
+        "off" = keep every matrix at its checkpoint shape (zeros are streamed)."""
         m, e, d = cfg.model, cfg.model.encoder, cfg.model.decoder
         if d.gqa_head_dim != HEAD_DIM or d.cross_head_dim != HEAD_DIM or e.head_dim != HEAD_DIM:
             raise hb.DiaHipError("the HIP attention kernels are built for head_dim 128 (Dia-1.6B)")
@@ -77,32 +80,83 @@ class DeviceWeights:
         self.dec_emb = torch.stack([dev(f"decoder.embeddings.{c}.weight") for c in range(cfg.data.channels)]).contiguous()
         self.dec_layers = []
         D = d.n_embd
+        QH, KVH, CH = d.gqa_query_heads, d.kv_heads, d.cross_query_heads
+        plans = []
+        for i in range(d.n_layer):
+            pl = cpt.plan_decoder_layer({k: v for k, v in sd.items() if k.startswith(f"decoder.layers.{i}.")},
+                                        f"decoder.layers.{i}.", QH, KVH, CH)
+            plans.append(pl if (compact != "off" and cpt.is_pruned(pl)) else None)
+        keep_logits = cpt.nonzero_rows(sd["decoder.logits_dense.weight"].reshape(D, -1))
+        logits_pruned = compact != "off" and not bool(keep_logits.all())
+        self.compacted = any(p is not None for p in plans) or logits_pruned
+        i32 = lambda t: t.to(device=device, dtype=torch.int32).contiguous()
+        ones_d = torch.ones(D, dtype=torch.bool)
+
+        def next_keep(i):          # input order of what consumes layer i's wo output
+            if i + 1 < d.n_layer:
+                return plans[i + 1].keep_qkv if plans[i + 1] is not None else None
+            return keep_logits if logits_pruned else None
+
         for i in range(d.n_layer):
             p = f"decoder.layers.{i}."
-            qkv = torch.cat([dev(p + f"self_attention.{n}_proj.weight").reshape(D, -1) for n in "qkv"], dim=1)
+            P = plans[i]
+            wq, wk, wv = (dev(p + f"self_attention.{n}_proj.weight").reshape(D, -1) for n in "qkv")
+            qkv = torch.cat([wq, wk, wv], dim=1)
+            o = dev(p + "self_attention.o_proj.weight").reshape(-1, D)
+            cq = dev(p + "cross_attention.q_proj.weight").reshape(D, -1)
+            co = dev(p + "cross_attention.o_proj.weight").reshape(-1, D)
             ck = dev(p + "cross_attention.k_proj.weight")[:, :, perm].reshape(e.n_embd, -1)
             cv = dev(p + "cross_attention.v_proj.weight").reshape(e.n_embd, -1)
-            self.dec_layers.append(dict(
-                g_sa=dev(p + "pre_sa_norm.weight").contiguous(), g_ca=dev(p + "pre_ca_norm.weight").contiguous(),
-                g_mlp=dev(p + "pre_mlp_norm.weight").contiguous(),
-                qkv=tile(qkv), o=tile(dev(p + "self_attention.o_proj.weight").reshape(-1, D)),
-                cq=tile(dev(p + "cross_attention.q_proj.weight").reshape(D, -1)),
-                co=tile(dev(p + "cross_attention.o_proj.weight").reshape(-1, D)),
-                ckv=tile(torch.cat([ck, cv], dim=1)),
-                wi=tile(lay.interleave_gate_up(dev(p + "mlp.wi_fused.weight"))), wo=tile(dev(p + "mlp.wo.weight")),
-            ))
+            ckv = torch.cat([ck, cv], dim=1)
+            wi3 = dev(p + "mlp.wi_fused.weight")
+            wo = dev(p + "mlp.wo.weight")
+            L = dict(g_sa=dev(p + "pre_sa_norm.weight").contiguous(), g_ca=dev(p + "pre_ca_norm.weight").contiguous(),
+                     g_mlp=dev(p + "pre_mlp_norm.weight").contiguous(),
+                     cmap_ca=None, cmap_mlp=None, cmap_next=None, smap_qkv=None, smap_cq=None, smap_ckv=None,
+                     hmap_self=None, hmap_cross=None)
+            nk = next_keep(i)
+            if nk is not None:
+                L["cmap_next"] = i32(cpt._cmap(nk))
+            if P is not None:
+                cols = lambda strips: (torch.tensor(strips, dtype=torch.long)[:, None] * 16 + torch.arange(16)[None, :]).reshape(-1).to(device)
+                s_qkv = (cpt.strips_of_heads(P.live_q_heads, 0) + cpt.strips_of_heads(P.live_kv_heads, QH * 128)
+                         + cpt.strips_of_heads(P.live_kv_heads, (QH + KVH) * 128))
+                qkv = qkv[P.keep_qkv.to(device)][:, cols(s_qkv)]
+                o = o[P.live_q_heads.to(device).repeat_interleave(128)]
+                s_cq = cpt.strips_of_heads(P.live_c_heads, 0)
+                cq = cq[P.keep_cq.to(device)][:, cols(s_cq)]
+                co = co[P.live_c_heads.to(device).repeat_interleave(128)]
+                s_ckv = cpt.strips_of_heads(P.live_c_heads, 0) + cpt.strips_of_heads(P.live_c_heads, CH * 128)
+                ckv = ckv[:, cols(s_ckv)]
+                hid = cpt.pad_hidden_keep(P.live_hidden).to(device)
+                wi3 = torch.stack([cpt.take_cols_idx(wi3[:, 0, :], hid), cpt.take_cols_idx(wi3[:, 1, :], hid)], dim=1)
+                wi3 = wi3[P.keep_wi.to(device)]
+                wo_c = wo[hid.clamp(min=0)].clone()
+                wo_c[hid < 0] = 0
+                wo = wo_c
+                L.update(cmap_ca=i32(cpt._cmap(P.keep_cq)), cmap_mlp=i32(cpt._cmap(P.keep_wi)),
+                         smap_qkv=i32(torch.tensor(s_qkv)), smap_cq=i32(torch.tensor(s_cq)), smap_ckv=i32(torch.tensor(s_ckv)),
+                         hmap_self=i32(cpt.head_map(P.live_q_heads)), hmap_cross=i32(cpt.head_map(P.live_c_heads)))
+            L.update(qkv=tile(qkv), o=tile(o), cq=tile(cq), co=tile(co), ckv=tile(ckv),
+                     wi=tile(lay.interleave_gate_up(wi3)), wo=tile(wo))
+            self.dec_layers.append(L)
+        self.cmap_first = i32(cpt._cmap(plans[0].keep_qkv)) if plans[0] is not None else None
         self.dec_norm = dev("decoder.norm.weight").contiguous()
-        self.logits = tile(dev("decoder.logits_dense.weight").reshape(D, -1))
+        lw = dev("decoder.logits_dense.weight").reshape(D, -1)
+        self.logits = tile(lw[keep_logits.to(device)] if logits_pruned else lw)
+        self.logits_cols = lw.shape[1]
         npos = max(cfg.data.audio_length, cfg.data.text_length) + 1
         cos, sin = lay.rope_tables(npos, HEAD_DIM, m.rope_min_timescale, m.rope_max_timescale)
         self.cos_t, self.sin_t = cos.to(device), sin.to(device)
 
     @classmethod
     def empty_like_config(cls, cfg: DiaConfig, device: torch.device) -> "DeviceWeights":
-        """Same tensors, zero-filled: the receive side of the multi-GPU weight broadcast."""
+        """Same tensors, zero-filled: the receive side of the multi-GPU weight broadcast (dense layout;
+        a compacted, i.e. structured-pruned, model has checkpoint-dependent shapes: every rank then
+        loads the checkpoint itself instead of receiving a broadcast)."""
         from .weights import param_shapes
         sd = {k: torch.zeros(shp, dtype=torch.float32, device=device) for k, shp in param_shapes(cfg).items()}
-        return cls(cfg, sd, device)
+        return cls(cfg, sd, device, compact="off")
 
     def decode_weight_bytes(self) -> int:
         """bf16 bytes one decode step streams (SURVEY.md §8d 'W'): every decoder matrix except the
@@ -233,6 +287,7 @@ class DecodeSession:
         e.emb, e.g, e.x = hb.ptr(self.w.dec_emb), hb.ptr(self.w.dec_layers[0]["g_sa"]), hb.ptr(self.x)
         e.P, e.p_plane_stride, e.p_ktiles = hb.ptr(self.planes_x), self.planes_x[0].numel(), self.xkt
         e.ssq_ld, e.ssq = self.rows_pad, hb.ptr(self.ssq)
+        e.cmap = hb.ptr(self.w.cmap_first)
         return e
 
     def _sample_args(self) -> hb.SampleArgs:
@@ -263,6 +318,8 @@ class DecodeSession:
             dl.g_sa, dl.g_ca, dl.g_mlp = hb.ptr(L["g_sa"]), hb.ptr(L["g_ca"]), hb.ptr(L["g_mlp"])
             dl.k_self, dl.v_self = hb.ptr(self.k_self[i]), hb.ptr(self.v_self[i])
             dl.k_cross, dl.v_cross = hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i])
+            for f in ("cmap_ca", "cmap_mlp", "cmap_next", "smap_qkv", "smap_cq", "hmap_self", "hmap_cross"):
+                setattr(dl, f, hb.ptr(L[f]))
         ed = hb.EngineDesc()
         ed.n_layer, ed.D, ed.F = n, self.D, self.F
         ed.q_heads, ed.kv_heads, ed.cq_heads = d.gqa_query_heads, d.kv_heads, d.cross_query_heads
@@ -328,7 +385,7 @@ class DecodeSession:
                                           hb.ptr(px), px[0].numel(), ekt, hb.ptr(ssq), Lp, st), "dia_embed_text")
 
                 def gemm(A, a_kt, W: TiledW, epi, *, ssq_in=None, out=None, ldo=0, gnext=None, P=None, p_kt=0,
-                         ssq_out=None, kv=None):
+                         ssq_out=None, kv=None, strip_map=None):
                     g = hb.GemmArgs()
                     g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), a_kt, Lb
                     g.W, g.KT, g.nstrips, g.epi = hb.ptr(W.t), W.kt, W.ns, epi
@@ -340,6 +397,7 @@ class DecodeSession:
                     if P is not None:
                         g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), p_kt
                     g.ssq_out = hb.ptr(ssq_out)
+                    g.strip_map = hb.ptr(strip_map)
                     if kv is not None:
                         g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = kv
                         g.cos_t, g.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
@@ -364,7 +422,8 @@ class DecodeSession:
                 # px now holds planes(x * encoder.norm.weight); ssq the row sums of squares of x
                 for i, DL in enumerate(w.dec_layers):
                     gemm(px, ekt, DL["ckv"], hb.EPI_CROSSKV, ssq_in=ssq,
-                         kv=(hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i]), self.kv_code, d.cross_query_heads, self.S, b))
+                         kv=(hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i]), self.kv_code, d.cross_query_heads, self.S, b),
+                         strip_map=DL["smap_ckv"])
                 if keep_encoder_out:
                     inv = torch.rsqrt(ssq[:, :Lb].sum(dim=0) / E + eps)
                     self.enc_out.append((x[:Lb] * inv[:, None] * w.enc_norm[None, :]).clone())

@@ -88,6 +88,13 @@ typedef struct {
   int32_t kv_batch_index;
   const float* cos_t;       /* [npos][64] */
   const float* sin_t;
+  /* structured-pruned (compacted) checkpoints — all optional, NULL = dense:
+   * cmap      RESID_EMIT: int32 [N]; column n of the residual stream is emitted at plane position
+   *           cmap[n] (the consumer's compacted K order) or dropped when cmap[n] < 0;
+   * strip_map SCALE_STORE / CROSSKV: int32 [nstrips]; compact strip s holds the 16 output columns
+   *           of original strip strip_map[s] (whole heads dropped by a later o_proj). */
+  const int32_t* cmap;
+  const int32_t* strip_map;
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
@@ -126,6 +133,9 @@ typedef struct {
    * tickets: n_rows*n_kv_heads int32, zero before the first launch (the kernel re-zeroes them). */
   float* scratch;
   int32_t* tickets;
+  /* int32 [n_kv_heads*group] or NULL: query head h is emitted at head position head_map[h] of the
+   * (compacted) o_proj input; < 0 = head pruned, nothing emitted */
+  const int32_t* head_map;
 } dia_attn_args;
 int dia_attn(const dia_attn_args* a, void* stream);
 int dia_attn_scratch_floats(int n_rows, int n_kv_heads, int kv_cap);
@@ -153,6 +163,7 @@ typedef struct {
   int32_t p_ktiles;
   int32_t ssq_ld;
   float* ssq;               /* [D/16][ssq_ld] */
+  const int32_t* cmap;      /* as dia_gemm_args.cmap (first layer's q/k/v input order) or NULL */
 } dia_embed_args;
 int dia_embed_tokens(const dia_embed_args* a, void* stream);
 
@@ -198,6 +209,14 @@ typedef struct {
   void *k_self, *v_self;                                 /* [R][kv_heads][T][128] */
   void *k_cross, *v_cross;                               /* [B][cq_heads][S][128] */
   int32_t kt_qkv, ns_qkv, kt_o, ns_o, kt_cq, ns_cq, kt_co, ns_co, kt_wi, ns_wi, kt_wo, ns_wo;
+  /* compaction maps (device int32, NULL = dense): */
+  const int32_t* cmap_ca;     /* emitted by self o_proj for the cross-q input order */
+  const int32_t* cmap_mlp;    /* emitted by cross o_proj for the wi_fused input order */
+  const int32_t* cmap_next;   /* emitted by wo for the next layer's q/k/v input order (or the logits head's) */
+  const int32_t* smap_qkv;    /* strip map of the q/k/v output */
+  const int32_t* smap_cq;     /* strip map of the cross-q output */
+  const int32_t* hmap_self;   /* head map of self-attention */
+  const int32_t* hmap_cross;  /* head map of cross-attention */
 } dia_dec_layer;
 
 typedef struct {

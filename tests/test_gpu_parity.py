@@ -231,3 +231,33 @@ def test_full_size_first_steps_vs_oracle():
         outs.append((s.results()[0].tokens.copy(), s.logits_host().copy()))
         s.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_structured_pruned_checkpoint_is_compacted_and_matches_reference(mid, golden):
+    """BASELINE config 4: a 50 % dim-0 structured-pruned checkpoint (the reference's own
+    pruning_utils produced the golden) loads as physically smaller tensors and reproduces the
+    reference's logits / token ids."""
+    from dia_hip.pruning import structured_prune_state_dict
+    cfg, sd, w_dense = mid
+    g = golden("ref_pruned_mid.npz")
+    psd, keep = structured_prune_state_dict(cfg, sd, amount=0.5, dim=0, n=2)
+    dev = torch.device("cuda:0")
+    wc = DeviceWeights(cfg, psd, dev)                       # compact="auto"
+    wz = DeviceWeights(cfg, psd, dev, compact="off")        # zeros streamed
+    assert wc.compacted and not wz.compacted
+    ratio = wc.decode_weight_bytes() / wz.decode_weight_bytes()
+    print(f"pruned mid: decode weight bytes {wc.decode_weight_bytes()} vs {wz.decode_weight_bytes()} (x{ratio:.3f})")
+    assert ratio < 0.45                                     # 50 % rows, plus dead heads / hidden units propagated
+    mt = int(g["max_tokens"])
+    text = TEXTS[0]
+    for w in (wc, wz):
+        s = DecodeSession(w, [encode_text(effective_text(text), cfg)], kv_dtype="f32", max_tokens=mt, seeds=[42])
+        s.prefill(); s.run(use_graph=True, poll=8)
+        r = s.results()[0]; s.close()
+        assert np.array_equal(r.tokens, g["tokens"])        # the reference's token buffer for the pruned model
+    # teacher-forced logits against the reference's recorded logits
+    nz = O.exp_noise(42, mt - 1, 9, 1028)
+    logits, res = teacher_forced(wc, cfg, [text], [g["tokens"]], [nz], mt)
+    for j, st in enumerate(g["logit_steps"]):
+        err = float(np.abs(logits[int(st)][0] - g["logits"][j]).max())
+        assert err <= LOGIT_TOL, (int(st), err)

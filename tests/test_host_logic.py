@@ -143,3 +143,29 @@ def test_checkpoint_io(tmp_path):
         W.check_state_dict(cfg, bad)
     with pytest.raises(FileNotFoundError):
         W.find_checkpoint_in_dir(str(tmp_path / "missing"))
+
+
+def test_compaction_plan_from_zeros():
+    from dia_hip import compact as cpt
+    from dia_hip.pruning import structured_prune_state_dict
+    cfg = C.mid_config()
+    sd = W.synthetic_state_dict(cfg, seed=1234, std=0.02)
+    psd, keep = structured_prune_state_dict(cfg, sd, amount=0.5, dim=0, n=2)
+    d = cfg.model.decoder
+    pre = "decoder.layers.1."
+    P = cpt.plan_decoder_layer(psd, pre, d.gqa_query_heads, d.kv_heads, d.cross_query_heads)
+    assert cpt.is_pruned(P)
+    # structure recovered from zeros == the kept indices of the pruning pass
+    kq = set(keep[pre + "self_attention.q_proj.weight"].tolist()) | set(keep[pre + "self_attention.k_proj.weight"].tolist()) \
+        | set(keep[pre + "self_attention.v_proj.weight"].tolist())
+    assert set(torch.nonzero(P.keep_qkv).flatten().tolist()) == kq
+    assert torch.nonzero(P.live_q_heads).flatten().tolist() == keep[pre + "self_attention.o_proj.weight"].tolist()
+    assert torch.nonzero(P.live_hidden).flatten().tolist() == keep[pre + "mlp.wo.weight"].tolist()
+    assert int(P.live_q_heads.sum()) == d.gqa_query_heads // 2 and int(P.live_hidden.sum()) == d.n_hidden // 2
+    cm = cpt._cmap(P.keep_cq)
+    assert cm.max().item() == int(P.keep_cq.sum()) - 1 and (cm[~P.keep_cq] == -1).all()
+    assert cpt.strips_of_heads(torch.tensor([False, True, False, True]), 256) == list(range(24, 32)) + list(range(40, 48))
+    idx = cpt.pad_hidden_keep(torch.tensor([True] * 5 + [False] * 11))
+    assert idx.tolist() == [0, 1, 2, 3, 4, -1, -1, -1]
+    dense = cpt.plan_decoder_layer(sd, pre, d.gqa_query_heads, d.kv_heads, d.cross_query_heads)
+    assert not cpt.is_pruned(dense)
