@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--pruned", type=float, default=0.0, help="structured dim-0 pruning amount applied to the synthetic checkpoint (BASELINE config 4: 0.5)")
+    ap.add_argument("--no-compact", action="store_true", help="with --pruned: stream the zeros instead of compacting")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,13 +94,16 @@ def main():
 
     # ---- weights: rank 0 builds + repacks, the other ranks receive the repacked tensors over RCCL
     t0 = time.time()
-    sd_gpu = synthetic_state_dict(cfg, seed=1234, std=0.02, device=dev) if rank == 0 else None
-    if rank == 0:
-        w = DeviceWeights(cfg, sd_gpu, dev)
+    sd_gpu = synthetic_state_dict(cfg, seed=1234, std=0.02, device=dev) if (rank == 0 or args.pruned > 0) else None
+    if args.pruned > 0:
+        from dia_hip.pruning import structured_prune_state_dict
+        sd_gpu, _ = structured_prune_state_dict(cfg, sd_gpu, amount=args.pruned, dim=0, n=2)     # offline_prune.py defaults
+    if rank == 0 or args.pruned > 0:
+        w = DeviceWeights(cfg, sd_gpu, dev, compact="off" if args.no_compact else "auto")
     else:
         w = DeviceWeights.empty_like_config(cfg, dev)
     bcast_s = 0.0
-    if world > 1:
+    if world > 1 and not args.pruned:
         torch.cuda.synchronize()
         tb = time.time()
         broadcast_weights(w, src=0)
@@ -152,7 +157,7 @@ def main():
         breakdown["sample_fsm_embed"] = round(float(prof[:, nl * 8 + 1].mean()) * 1e3, 2)
         breakdown["unit"] = "us between per-launch HIP events of one eager step (each interval carries ~3 us of event/boundary overhead)"
         wi_ms = sess.time_wi_launches(reps=5) * 1e3          # dispatch-level start/stop events per launch
-        wi_bytes = w.dec_layers[0]["wi"].nbytes                  # algorithmic bytes of the dominant kernel
+        wi_bytes = sum(L["wi"].nbytes for L in w.dec_layers) / len(w.dec_layers)   # algorithmic bytes of the dominant kernel
         kname = ("k_gemv_small<NW=16,KPW=4,RS=%d,MULTI>" % (2 if 2 * args.batch <= 2 else 4)) if 2 * args.batch <= 4 \
             else "k_gemm<MT=%d,NW=4,KPW=16>" % min(4, (2 * args.batch + 15) // 16)
         roof = {"bound": "hbm", "kernel": kname + " on wi_fused [2048 x 16384] bf16 (SwiGLU epilogue), 18 launches/step",
@@ -180,13 +185,13 @@ def main():
         "metric": "audio-codec frames/sec (Dia-1.6B decode, whole job)", "value": round(value, 2), "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"Dia-1.6B bf16 weights, {args.kv} K/V, batch {args.batch} per GPU, {K} decode steps, "
+        "config": {"workload": f"Dia-1.6B{' %d%%-structured-pruned (dim 0, compacted=%s)' % (round(args.pruned * 100), not args.no_compact) if args.pruned else ''} bf16 weights, {args.kv} K/V, batch {args.batch} per GPU, {K} decode steps, "
                                f"text bytes {sess.lens}, cfg 3.0 / T 1.3 / top-p 0.95 / top-k 35, hipGraph={use_graph}",
                    "batch_per_gpu": args.batch, "parallelism": f"dp{world}" if world > 1 else "single"},
         "frames_per_s_per_gpu": round(value / world, 2), "rtf_per_gpu": round(value / world / args.batch / FRAME_RATE, 3),
         "rtf_aggregate": round(value / FRAME_RATE, 2),
         "prefill_s": round(prefill_s, 4), "weights_load_s": round(load_s, 2), "weights_bcast_s": round(bcast_s, 3),
-        "device_ms_per_step": round(dev_ms / K, 4),
+        "device_ms_per_step": round(dev_ms / K, 4), "decode_weight_bytes": int(w.decode_weight_bytes()),
         "step_roofline": {"bytes_per_step": int(step_bytes), "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
         "launch_breakdown": breakdown,

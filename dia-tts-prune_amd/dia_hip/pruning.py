@@ -46,12 +46,12 @@ def structured_prune_state_dict(cfg: DiaConfig, sd: Dict[str, torch.Tensor], amo
         other = [a for a in range(w.dim()) if a != dim]
         norm = torch.norm(w, p=n, dim=other)
         keep_idx = torch.topk(norm, k=n_keep, largest=True).indices
-        mask = torch.zeros(size, dtype=torch.bool)
+        mask = torch.zeros(size, dtype=torch.bool, device=w.device)
         mask[keep_idx] = True
         shape = [1] * w.dim()
         shape[dim] = size
         out[name] = (w * mask.view(shape)).to(sd[name].dtype)
-        kept[name] = torch.nonzero(mask).flatten().numpy().astype(np.int32)
+        kept[name] = torch.nonzero(mask).flatten().cpu().numpy().astype(np.int32)
     return out, kept
 
 
