@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--prefetch", type=int, default=0, help="weight prefetch lookahead in launches (experiment)")
     ap.add_argument("--pruned", type=float, default=0.0, help="structured dim-0 pruning amount applied to the synthetic checkpoint (BASELINE config 4: 0.5)")
     ap.add_argument("--no-compact", action="store_true", help="with --pruned: stream the zeros instead of compacting")
     args = ap.parse_args()
@@ -115,6 +116,8 @@ def main():
     ids = [encode_text(effective_text(t), cfg) for t in texts]
     seeds = [42 + 1000 * rank + i for i in range(args.batch)]
     sess = DecodeSession(w, ids, kv_dtype=args.kv, max_tokens=max_tokens, seeds=seeds, ignore_eos=True)
+    if args.prefetch > 0:
+        sess.set_prefetch(args.prefetch)
     tp = time.time()
     sess.prefill()
     sess.sync()

@@ -8,6 +8,8 @@
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
 #include <vector>
+#include <algorithm>
+#include <utility>
 
 struct dia_engine {
   dia_engine_desc d;
@@ -17,10 +19,30 @@ struct dia_engine {
   hipGraphExec_t exec = nullptr;
   int launches = 0;
   std::vector<hipEvent_t> prof;   // when non-empty: one event recorded after every launch (profile step)
+  // weight prefetch beside the chain (graph mode): launch i+lookahead's weights are pulled into the
+  // Infinity Cache by a side stream as soon as launch i has been issued
+  int pf_lookahead = 0;
+  bool pf_capturing = false;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> pf_ev;
+  std::vector<std::pair<const void*, long>> pf_w;   // per launch: weight pointer and bytes (null for attention)
 };
+
+int dia_prefetch_launch(const void* ptr, long nbytes, int nblocks, hipStream_t st);
+static int ensure_sink();
 
 static inline void mark(dia_engine* e, int i) {
   if (!e->prof.empty() && i + 1 < (int)e->prof.size()) (void)hipEventRecord(e->prof[i + 1], e->stream);
+  if (e->pf_capturing) {
+    const int j = i + e->pf_lookahead;
+    if (j < (int)e->pf_w.size() && e->pf_w[j].first != nullptr) {
+      (void)hipEventRecord(e->pf_ev[i], e->stream);
+      (void)hipStreamWaitEvent(e->side, e->pf_ev[i], 0);
+      const long bytes = e->pf_w[j].second;
+      const int nb = (int)std::min<long>(512, std::max<long>(32, bytes / (256 * 16 * 8)));
+      (void)dia_prefetch_launch(e->pf_w[j].first, bytes, nb, e->side);
+    }
+  }
 }
 
 int dia_kernels_init_once() {
@@ -165,9 +187,38 @@ extern "C" int dia_engine_decode(dia_engine* e, int n_steps, int use_graph) {
   }
   if (!e->exec) {
     if (e->stream == nullptr) return dia_fail(DIA_E_STATE, "dia_engine_decode: graph capture needs a non-default stream");
+    if (e->pf_lookahead > 0) {
+      int rc0 = ensure_sink();
+      if (rc0) return rc0;
+      const dia_engine_desc& d = e->d;
+      e->pf_w.clear();
+      for (int l = 0; l < d.n_layer; ++l) {
+        const dia_dec_layer& L = e->layers[l];
+        auto add = [&](const void* w, int kt, int ns) { e->pf_w.push_back({w, (long)kt * ns * 1024}); };
+        add(L.w_qkv, L.kt_qkv, L.ns_qkv); e->pf_w.push_back({nullptr, 0});
+        add(L.w_o, L.kt_o, L.ns_o); add(L.w_cq, L.kt_cq, L.ns_cq); e->pf_w.push_back({nullptr, 0});
+        add(L.w_co, L.kt_co, L.ns_co); add(L.w_wi, L.kt_wi, L.ns_wi); add(L.w_wo, L.kt_wo, L.ns_wo);
+      }
+      e->pf_w.push_back({d.w_logits, (long)d.kt_logits * d.ns_logits * 1024});
+      e->pf_w.push_back({nullptr, 0});
+      if (!e->side && hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) return dia_fail(DIA_E_HIP, "hipStreamCreate(side)");
+      e->pf_ev.resize(e->pf_w.size() + 2);
+      for (auto& ev : e->pf_ev)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return dia_fail(DIA_E_HIP, "hipEventCreate(prefetch)");
+    }
     hipError_t he = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
     if (he != hipSuccess) return dia_fail_hip(he, "hipStreamBeginCapture");
+    if (e->pf_lookahead > 0) {       // fork the side stream into the capture
+      (void)hipEventRecord(e->pf_ev[e->pf_w.size()], e->stream);
+      (void)hipStreamWaitEvent(e->side, e->pf_ev[e->pf_w.size()], 0);
+      e->pf_capturing = true;
+    }
     int rc = enqueue_step(e, true);
+    if (e->pf_lookahead > 0) {       // join
+      e->pf_capturing = false;
+      (void)hipEventRecord(e->pf_ev[e->pf_w.size() + 1], e->side);
+      (void)hipStreamWaitEvent(e->stream, e->pf_ev[e->pf_w.size() + 1], 0);
+    }
     he = hipStreamEndCapture(e->stream, &e->graph);
     if (rc) return rc;
     if (he != hipSuccess) return dia_fail_hip(he, "hipStreamEndCapture");
@@ -243,13 +294,30 @@ __global__ __launch_bounds__(256) void k_prefetch(const uint4* __restrict__ p, l
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u && sink) *sink = 1;
 }
 
-extern "C" int dia_prefetch(const void* ptr, int64_t nbytes, int nblocks, void* stream) {
-  if (!ptr || nbytes <= 0 || nblocks <= 0) return dia_fail(DIA_E_ARG, "dia_prefetch: bad argument");
-  static unsigned* sink = nullptr;
-  if (!sink) {
-    hipError_t e = hipMalloc(&sink, 4);
+static unsigned* g_sink = nullptr;
+static int ensure_sink() {
+  if (!g_sink) {
+    hipError_t e = hipMalloc(&g_sink, 4);
     if (e != hipSuccess) return dia_fail_hip(e, "hipMalloc(sink)");
   }
-  hipLaunchKernelGGL(k_prefetch, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)ptr, (long)(nbytes / 16), sink);
+  return DIA_OK;
+}
+
+int dia_prefetch_launch(const void* ptr, long nbytes, int nblocks, hipStream_t st) {
+  hipLaunchKernelGGL(k_prefetch, dim3(nblocks), dim3(256), 0, st, (const uint4*)ptr, (long)(nbytes / 16), g_sink);
   return dia_check_launch("k_prefetch");
+}
+
+extern "C" int dia_prefetch(const void* ptr, int64_t nbytes, int nblocks, void* stream) {
+  if (!ptr || nbytes <= 0 || nblocks <= 0) return dia_fail(DIA_E_ARG, "dia_prefetch: bad argument");
+  int rc = ensure_sink();
+  if (rc) return rc;
+  return dia_prefetch_launch(ptr, (long)nbytes, nblocks, (hipStream_t)stream);
+}
+
+extern "C" int dia_engine_set_prefetch(dia_engine* e, int lookahead) {
+  if (!e || lookahead < 0) return dia_fail(DIA_E_ARG, "dia_engine_set_prefetch: bad argument");
+  if (e->exec) return dia_fail(DIA_E_STATE, "dia_engine_set_prefetch: the step graph is already captured");
+  e->pf_lookahead = lookahead;
+  return DIA_OK;
 }

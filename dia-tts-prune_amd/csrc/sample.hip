@@ -133,6 +133,13 @@ __device__ __forceinline__ int wave_argmax(float bv, int bi) {
   return bi;
 }
 
+#ifdef DIA_DBG_STAMPS
+__device__ long long g_sstamps[16];
+#define SSTAMP(i) do { if (threadIdx.x == 64) g_sstamps[i] = wall_clock64(); } while (0)
+#else
+#define SSTAMP(i) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int preds[MAXC];
@@ -151,28 +158,30 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
   unsigned short* li = reinterpret_cast<unsigned short*>(sp + VCAP);                // [VCAP] survivor indices
   unsigned short* rk = li + VCAP;                                                   // [VCAP] rank by vocab index
 
+  SSTAMP(0);
   if (!done && c < p.C) {
     const int n = cur - 1;                                                          // executed steps so far
     const float* un = p.logits + (long)(2 * b) * p.ld_logits + c * p.V;
     const float* co = p.logits + (long)(2 * b + 1) * p.ld_logits + c * p.V;
     float lg[NV], qn[NV];
-    const float* q = (p.temperature != 0.0f) ? p.noise + (((long)b * p.noise_steps + n) * p.C + c) * p.V : nullptr;
+    // every load of this wave is issued up front on clamped indices (no per-element branches: a
+    // conditional load makes hipcc wait for it on the spot), selections happen afterwards
+    const bool use_noise = p.temperature != 0.0f;
+    const float* q = use_noise ? p.noise + (((long)b * p.noise_steps + n) * p.C + c) * p.V : co;
+    float cv[NV], uv[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {       // Exp(1) variates requested together with the logits
-      const int v = lane + 64 * i;
-      qn[i] = (q != nullptr && v < p.V) ? q[v] : 1.0f;
+    for (int i = 0; i < NV; ++i) {
+      const int v = min(lane + 64 * i, p.V - 1);
+      cv[i] = co[v]; uv[i] = un[v]; qn[i] = q[v];
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = lane + 64 * i;
-      float x = -INFINITY;
-      if (v < p.V) {
-        const float cv = co[v], uv = un[v];
-        const float t = cv - uv;
-        x = cv + p.cfg_scale * t;                                                   // model.py:457
-        if (v == p.pad || v == p.bos || (c > 0 && v == p.eos)) x = -INFINITY;       // model.py:462-472
-      }
+      const float t = cv[i] - uv[i];
+      float x = cv[i] + p.cfg_scale * t;                                            // model.py:457
+      if (v >= p.V || v == p.pad || v == p.bos || (c > 0 && v == p.eos)) x = -INFINITY;   // model.py:462-472
       lg[i] = x;
+      if (!use_noise) qn[i] = 1.0f;
     }
     int choice;
     if (p.temperature == 0.0f) {                                                    // model.py:38-40
@@ -186,6 +195,7 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
     } else {
 #pragma unroll
       for (int i = 0; i < NV; ++i) lg[i] = lg[i] / p.temperature;                   // model.py:43
+      SSTAMP(1);
       // ---- top-k: k-th largest value by bitwise search on order-preserving keys (model.py:46-52)
       if (p.top_k > 0) {
         const int k = min(p.top_k, p.V);
@@ -204,6 +214,7 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) if (key[i] < pre) lg[i] = -INFINITY;
       }
+      SSTAMP(2);
       // ---- top-p (model.py:56-70)
       if (p.top_p < 1.0f) {
         float m = -INFINITY;
@@ -240,9 +251,23 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
           rk[is] = (unsigned short)r;
         }
         __builtin_amdgcn_wave_barrier();
-        // sequential cumulative sum in sorted order, accumulated in double like torch.cumsum on CPU
+        // cumulative sum in sorted order, accumulated in double like torch.cumsum on CPU.  Up to 64
+        // survivors (the usual case after top-k): a wave inclusive scan — in double the scan order moves the
+        // sum by ~1e-16 relative, far below the fp32 rounding applied before the comparison.
         int keep = ns;
-        if (lane == 0) {
+        if (ns <= 64) {
+          double cum = (lane < ns) ? (double)sp[lane] : 0.0;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(cum, o, 64);
+            if (lane >= o) cum += up;
+          }
+          // entry r+1 is removed iff float(cum[r]) > top_p; removal is monotone in r
+          const unsigned long long over = __ballot(lane < ns && (float)cum > p.top_p);
+          const int first = over ? (__ffsll((long long)over) - 1) : ns;          // smallest r with cum[r] > top_p
+          keep = min(ns, first + 1);
+          if (ns == 0) keep = 0;
+        } else if (lane == 0) {
           double cum = 0.0;
           keep = 1;
           for (int r = 0; r + 1 < ns; ++r) {
@@ -250,7 +275,6 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
             if ((float)cum > p.top_p) break;          // entry r+1 is removed, and all after it
             keep = r + 2;
           }
-          if (ns == 0) keep = 0;
         }
         keep = __shfl(keep, 0, 64);
 #pragma unroll
@@ -259,6 +283,7 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
           else lg[i] = -INFINITY;                       // sorts after every survivor; cum there > top_p
         }
       }
+      SSTAMP(3);
       // ---- final softmax + multinomial as argmax(p / q) (model.py:73-82)
       float m2 = -INFINITY;
 #pragma unroll
@@ -279,10 +304,12 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
       }
       choice = wave_argmax(bv, bi);
     }
+    SSTAMP(4);
     if (lane == 0) preds[c] = choice;
   }
   __syncthreads();
 
+  SSTAMP(5);
   // ---- token state machine: wave 0, lane i = channel i (all global accesses issued in parallel) ----
   if (c == 0) {
     int go = 0;
@@ -325,7 +352,9 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
     if (lane == 0) go_next = go;
   }
   __syncthreads();
+  SSTAMP(6);
   if (go_next) embed_rows(p.e, b, tok_next, tid, blockDim.x);
+  SSTAMP(7);
 }
 
 }  // namespace
@@ -357,6 +386,12 @@ extern "C" int dia_embed_text(const int32_t* ids, int L, const float* table, int
                      (bf16_raw*)P, (long)p_plane_stride, p_ktiles, ssq, ssq_ld);
   return dia_check_launch("k_embed_text");
 }
+
+#ifdef DIA_DBG_STAMPS
+extern "C" int dia_dbg_sstamps(long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sstamps), sizeof(long long) * 16) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int dia_sample_init() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);

@@ -439,6 +439,9 @@ class DecodeSession:
             raise hb.DiaHipError("decode() before prefill()")
         hb.check(hb.lib().dia_engine_decode(self._engine, int(n_steps), int(bool(use_graph))), "dia_engine_decode")
 
+    def set_prefetch(self, lookahead: int):
+        hb.check(hb.lib().dia_engine_set_prefetch(self._engine, int(lookahead)), "dia_engine_set_prefetch")
+
     def step_logits_only(self):
         hb.check(hb.lib().dia_engine_step_logits_only(self._engine), "dia_engine_step_logits_only")
 

@@ -255,6 +255,9 @@ int dia_engine_create(const dia_engine_desc* d, void* stream, dia_engine** out);
 int dia_engine_destroy(dia_engine* e);
 /* enqueue `n_steps` decode steps; use_graph != 0 replays a captured hipGraph of one step */
 int dia_engine_decode(dia_engine* e, int n_steps, int use_graph);
+/* before the first graph decode: prefetch the weights of launch i+lookahead into the Infinity Cache
+ * on a side branch of the step graph as soon as launch i has been issued (0 = off) */
+int dia_engine_set_prefetch(dia_engine* e, int lookahead);
 /* enqueue ONE decode step stopping after the logits GEMM (no sampling); for per-kernel timing */
 int dia_engine_step_logits_only(dia_engine* e);
 /* run ONE eager decode step with a HIP event recorded on the engine's stream after every launch and
