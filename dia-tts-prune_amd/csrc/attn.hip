@@ -5,15 +5,15 @@
 // materialised here: one workgroup serves a kv head and its `G` query heads) and
 // F.scaled_dot_product_attention (layers.py:329-337).
 //
-// Grid = (kv head, query row, key chunk).  A workgroup owns CHUNK = 128 consecutive keys of one
-// (row, kv head): 16 lanes per key (8 dims each, one 16 B load for bf16 K / two for fp32), four keys
-// per lane group with all loads in flight at once, G dot products, xor-butterfly over the 16 lanes,
-// chunk-local softmax numerators in LDS, then P.V with the same key->lane-group mapping, reduced over
-// the lane groups by shuffles and LDS in a fixed order.  A (row, head) with one active chunk emits
-// directly.  With several, every chunk publishes {max, sum, unnormalised output} to a scratch slab and
-// the LAST arriver (agent-scope release / ticket / acquire, guide §6 G16) merges the slabs in chunk
-// order — deterministic regardless of arrival order — and emits.  The grid is static (hipGraph): chunks
-// beyond the current length exit at once.
+// Grid = (kv head, query row, key split).  A workgroup is 4 waves; every 16-lane group of a wave runs
+// its OWN online softmax over its keys (8 dims of K/V per lane: one 16 B load per key and lane for bf16,
+// two for fp32; four keys per group per round, all eight loads in flight together), so the key loop has
+// no LDS traffic and no barrier.  Keys are dealt in units of 64 (one per wave-round); workgroup z of NZ
+// takes units z, z+NZ, ...  At the end the 4 groups of a wave merge by shuffles, the 4 waves through LDS,
+// and — when NZ > 1 — the workgroups through a scratch slab: every workgroup publishes {max, sum,
+// unnormalised output} and the LAST arriver (agent-scope release / ticket / acquire, guide §6 G16) merges
+// the slabs in split order — deterministic regardless of arrival order — and emits.  The grid is static
+// (hipGraph): splits beyond the current length exit at once.
 // The output leaves as three bf16 planes in MFMA A-operand order for the o_proj GEMM.
 #include "common.hpp"
 #include "../../include/dia_hip.h"
@@ -23,10 +23,11 @@
 namespace {
 
 constexpr int HD = 128;
-constexpr int NT = 512;            // threads per workgroup
-constexpr int NGRP = NT / 16;      // key groups
-constexpr int U = 4;               // keys per lane group (independent loads in flight)
-constexpr int CHUNK = NGRP * U;    // 128 keys per workgroup
+constexpr int NT = 256;            // threads per workgroup (4 waves)
+constexpr int NWV = NT / 64;
+constexpr int U = 4;               // keys per lane group per round (independent loads in flight)
+constexpr int UNIT = NWV * 16;     // 64 keys per workgroup round: 16 per wave, 4 per lane group
+constexpr int CHUNK = 128;         // scratch sizing granule: at most one split per 128 keys of capacity
 constexpr int SLAB = 2 * 8 + 4 * HD;   // floats per (row, head, chunk): m[G<=4], l[G<=4] (padded to 8 each), o[G][128]
 
 struct AttnK {
@@ -43,9 +44,8 @@ struct AttnK {
 template <typename KVT, int G>
 __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
   __shared__ __attribute__((aligned(16))) float q_s[G * HD];
-  __shared__ float sc[G * CHUNK];
-  __shared__ float part[(NT / 64) * G * HD];
-  __shared__ float m_s[8], l_s[8], alpha_s[8];
+  __shared__ float part[NWV * G * HD];
+  __shared__ float pm_s[NWV * 8], pl_s[NWV * 8];
   __shared__ float knew_s[HD], vnew_s[HD];
   __shared__ int last_s;
 
@@ -66,32 +66,31 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
     qrow = blockIdx.y; kvrow = 0; pos = qrow; nkeys = p.enc_len;
     head_row = qrow;
   }
-  // The pair's keys are cut into 128-key blocks; this workgroup takes blocks chunk, chunk+NZ, ... (NZ =
-  // gridDim.z is static for the graph) and carries a running softmax across them.
   const int NZ = gridDim.z;
-  const int nblocks = max(1, (nkeys + CHUNK - 1) / CHUNK);
-  if (chunk >= nblocks) return;                       // uniform: nothing to do for this workgroup yet
+  const int nunits = max(1, (nkeys + UNIT - 1) / UNIT);
+  if (chunk >= nunits) return;                        // uniform: nothing to do for this workgroup yet
+  const int nchunks = min(NZ, nunits);                // workgroups that publish a partial for this pair
   if (p.head_map) {                                   // every query head of this kv head pruned: no work
     bool any_live = false;
 #pragma unroll
     for (int g = 0; g < G; ++g) any_live |= p.head_map[kvh * G + g] >= 0;
     if (!any_live && !(p.mode == DIA_ATTN_SELF)) return;      // (self: the k/v append below must still happen)
   }
-  const int nchunks = min(NZ, nblocks);               // workgroups that publish a partial for this pair
 
   KVT* Kc = reinterpret_cast<KVT*>(p.kc) + ((long)kvrow * p.n_kv_heads + kvh) * p.kv_cap * HD;
   KVT* Vc = reinterpret_cast<KVT*>(p.vc) + ((long)kvrow * p.n_kv_heads + kvh) * p.kv_cap * HD;
-  const int grp = tid >> 4, sub = tid & 15;
+  const int gr = lane >> 4, sub = lane & 15;           // lane group inside the wave, 8-dim slice
+  const int klast = max(nkeys - 1, 0);
   float kv[U][8], vv[U][8];
-  auto load_block = [&](int blk) {     // K and V of one block: 4 keys per lane group, all loads in flight
-    const int b0 = blk * CHUNK, blast = max(min(nkeys, b0 + CHUNK) - 1, b0);
+  // unit u, wave w, group gr, round-key uu  ->  key u*64 + w*16 + uu*4 + gr (4 consecutive keys per load instruction)
+  auto load_unit = [&](int unit) {
+    const int base = unit * UNIT + w * 16 + gr;
 #pragma unroll
-    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Kc + (long)min(b0 + grp + u * NGRP, blast) * HD + sub * 8, kv[u]);
+    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Kc + (long)min(base + u * 4, klast) * HD + sub * 8, kv[u]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Vc + (long)min(b0 + grp + u * NGRP, blast) * HD + sub * 8, vv[u]);
+    for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Vc + (long)min(base + u * 4, klast) * HD + sub * 8, vv[u]);
   };
-  // K and V do not depend on q: request the first block before the prologue so the latencies overlap
-  load_block(chunk);
+  load_unit(chunk);      // K/V do not depend on q: in flight during the prologue
 
   // ---- prologue: RoPE(q); the workgroup that owns the new slot also ropes k and appends k, v -------
   const float* qr = p.q + (long)qrow * p.ldq;
@@ -103,8 +102,8 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
     q_s[g * HD + d] = x1 * c - x2 * s;
     q_s[g * HD + d + 64] = x1 * s + x2 * c;
   }
-  const int slot_blk = slot >= 0 ? slot / CHUNK : -1;
-  const bool owns_slot = p.mode == DIA_ATTN_SELF && slot_blk >= 0 && (slot_blk % NZ) == chunk;
+  const int slot_unit = slot >= 0 ? slot / UNIT : -1;
+  const bool owns_slot = p.mode == DIA_ATTN_SELF && slot_unit >= 0 && (slot_unit % NZ) == chunk;
   if (owns_slot && tid >= NT - 64) {
     const int d = tid - (NT - 64);
     const float* kh = qr + p.k_off + kvh * HD;
@@ -119,7 +118,6 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
     KVElem<KVT>::store(Vc + (long)slot * HD + d, v1v);
     KVElem<KVT>::store(Vc + (long)slot * HD + d + 64, v2v);
   }
-  if (tid < 8) { m_s[tid] = -INFINITY; l_s[tid] = 0.f; }
   __syncthreads();
 
   float qreg[G][8];
@@ -128,107 +126,126 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) qreg[g][j] = q_s[g * HD + sub * 8 + j];
   const float scale = 0.08838834764831845f;   // 1/sqrt(128)
-  float acc[G][8];
+  float acc[G][8], mrun[G], lrun[G];           // this lane group's running softmax state
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+  for (int g = 0; g < G; ++g) {
+    mrun[g] = -INFINITY; lrun[g] = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+  }
 
-  for (int blk = chunk; blk < nblocks; blk += NZ) {
-    const int k0 = blk * CHUNK, k1 = min(nkeys, k0 + CHUNK);
-    if (blk != chunk) load_block(blk);
-    if (owns_slot && blk == slot_blk) {     // loads of the slot written this step are stale: take the LDS copy
+  constexpr bool PREFETCH = G <= 2;            // 64 more VGPRs: fits next to G <= 2 accumulators only
+  float kvn[PREFETCH ? U : 1][8], vvn[PREFETCH ? U : 1][8];
+  for (int unit = chunk; unit < nunits; unit += NZ) {
+    const int nu = unit + NZ;
+    if constexpr (PREFETCH) {
+      if (nu < nunits) {                       // next unit's K/V stream while this one computes
+        const int nb = nu * UNIT + w * 16 + gr;
+#pragma unroll
+        for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Kc + (long)min(nb + u * 4, klast) * HD + sub * 8, kvn[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) KVElem<KVT>::load8(Vc + (long)min(nb + u * 4, klast) * HD + sub * 8, vvn[u]);
+      }
+    } else {
+      if (unit != chunk) load_unit(unit);
+    }
+    const int base = unit * UNIT + w * 16 + gr;
+    if (owns_slot && unit == slot_unit) {      // loads of the slot written this step are stale: take the LDS copy
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (k0 + grp + u * NGRP == slot) {
+        if (base + u * 4 == slot) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { kv[u][j] = knew_s[sub * 8 + j]; vv[u][j] = vnew_s[sub * 8 + j]; }
         }
     }
-    // scores of the block
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int kl = grp + u * NGRP;
+    for (int g = 0; g < G; ++g) {
+      float sc[U];
+      float mnew = mrun[g];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
+      for (int u = 0; u < U; ++u) {
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += qreg[g][j] * kv[u][j];
-        s += __shfl_xor(s, 8, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 1, 64);
-        if (sub == 0) sc[g * CHUNK + kl] = (k0 + kl < k1) ? s * scale : -INFINITY;
+        s = row16_sum(s);
+        sc[u] = (base + u * 4 < nkeys) ? s * scale : -INFINITY;
+        mnew = fmaxf(mnew, sc[u]);
+      }
+      const float alpha = (mrun[g] == -INFINITY) ? 0.f : __expf(mrun[g] - mnew);
+      float pu[U], ls = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) { pu[u] = (sc[u] == -INFINITY) ? 0.f : __expf(sc[u] - mnew); ls += pu[u]; }
+      lrun[g] = lrun[g] * alpha + ls;
+      mrun[g] = mnew;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = acc[g][j] * alpha;
+#pragma unroll
+        for (int u = 0; u < U; ++u) a += pu[u] * vv[u][j];
+        acc[g][j] = a;
       }
     }
-    __syncthreads();
-    // running softmax (wave g handles query head g): new max, rescale factor for what is accumulated
-    if (w < G) {
-      float* s = sc + w * CHUNK;
-      const float a = s[lane], b = s[lane + 64];
-      const float mold = m_s[w];
-      const float mnew = fmaxf(mold, wave_max(fmaxf(a, b)));
-      const bool any = nkeys > 0;
-      const float ea = any ? expf(a - mnew) : 0.f, eb = any ? expf(b - mnew) : 0.f;   // exp(-inf) = 0 for padding keys
-      s[lane] = ea; s[lane + 64] = eb;
-      const float lb = wave_sum(ea + eb);
-      if (lane == 0) {
-        const float alpha = (mold == -INFINITY) ? 0.f : expf(mold - mnew);
-        alpha_s[w] = alpha;
-        l_s[w] = l_s[w] * alpha + lb;
-        m_s[w] = mnew;
+    if constexpr (PREFETCH) {
+      if (nu < nunits) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { kv[u][j] = kvn[u][j]; vv[u][j] = vvn[u][j]; }
       }
     }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float al = alpha_s[g];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[g][j] *= al;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int kl = grp + u * NGRP;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float pk = sc[g * CHUNK + kl];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[g][j] += pk * vv[u][j];
-      }
-    }
-    if (blk + NZ < nblocks) __syncthreads();      // sc / alpha_s are rewritten by the next block
   }
+
+  // ---- merge the 4 lane groups of the wave (shuffles), then the waves (LDS), both in fixed order -----
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+  for (int g = 0; g < G; ++g) {
+    float mw = mrun[g];
+    mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
+    mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+    const float f = (mrun[g] == -INFINITY) ? 0.f : expf(mrun[g] - mw);
+    float lw = lrun[g] * f;
+    lw += __shfl_xor(lw, 16, 64);
+    lw += __shfl_xor(lw, 32, 64);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float a = acc[g][j];
+      float a = acc[g][j] * f;
       a += __shfl_xor(a, 16, 64);
       a += __shfl_xor(a, 32, 64);
       acc[g][j] = a;
     }
+    mrun[g] = mw; lrun[g] = lw;
+  }
   if (lane < 16) {
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int g = 0; g < G; ++g) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) part[(w * G + g) * HD + sub * 8 + j] = acc[g][j];
+      if (sub == 0) { pm_s[w * 8 + g] = mrun[g]; pl_s[w * 8 + g] = lrun[g]; }
+    }
   }
   __syncthreads();
 
-  // ---- G*16 threads own 8 output dims each: sum over the waves in fixed order -------------------------
+  // ---- G*16 threads own 8 output dims each ------------------------------------------------------------
   const bool o_thread = tid < G * 16;
   const int og = tid >> 4, od0 = (tid & 15) * 8;
   float o[8];
+  float M = 0.f, Lsum = 1.f;
   if (o_thread) {
+    float mm = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float a = 0.f;
+    for (int ww = 0; ww < NWV; ++ww) mm = fmaxf(mm, pm_s[ww * 8 + og]);
+    float L2 = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < NT / 64; ++ww) a += part[(ww * G + og) * HD + od0 + j];
-      o[j] = a;
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NWV; ++ww) {
+      const float pmw = pm_s[ww * 8 + og];
+      const float f = (pmw == -INFINITY) ? 0.f : expf(pmw - mm);
+      L2 += pl_s[ww * 8 + og] * f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += part[(ww * G + og) * HD + od0 + j] * f;
     }
+    M = mm; Lsum = L2;
   }
-  float M = o_thread ? m_s[og] : 0.f, Lsum = o_thread ? l_s[og] : 1.f;
 
   if (nchunks > 1) {
     // publish this chunk's slab, take a ticket; the last arriver merges
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const float f = (c0 + u < nchunks) ? expf(fm[u] - mm) : 0.f;
+          const float f = (c0 + u < nchunks && fm[u] != -INFINITY) ? expf(fm[u] - mm) : 0.f;
           L2 += lc[u] * f;
           o[0] += oa[u].x * f; o[1] += oa[u].y * f; o[2] += oa[u].z * f; o[3] += oa[u].w * f;
           o[4] += ob[u].x * f; o[5] += ob[u].y * f; o[6] += ob[u].z * f; o[7] += ob[u].w * f;
@@ -342,8 +359,9 @@ extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
   if (a->p_plane_stride % 8 != 0) return dia_fail(DIA_E_ARG, "dia_attn: plane stride must be a multiple of 8");
   const int cap_keys = a->mode == DIA_ATTN_ENC ? a->enc_len : a->kv_cap;
   const int cap_chunks = (cap_keys + CHUNK - 1) / CHUNK;
-  // key-split factor: enough workgroups to cover the 256 CUs once, never more than one per 128-key block
-  int max_chunks = (256 + a->n_rows * a->n_kv_heads - 1) / (a->n_rows * a->n_kv_heads);
+  // key-split factor: ~2 workgroups of 4 waves per CU, never more than one split per 128 keys of
+  // capacity (the scratch sizing granule), and each split at least one 64-key unit
+  int max_chunks = (512 + a->n_rows * a->n_kv_heads - 1) / (a->n_rows * a->n_kv_heads);
   if (const char* e = getenv("DIA_DBG_NZ")) { if (atoi(e) > 0) max_chunks = atoi(e); }
   if (max_chunks > cap_chunks) max_chunks = cap_chunks;
   if (max_chunks < 1) max_chunks = 1;
