@@ -128,6 +128,9 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g = {};
     g.A = d.planes_h; g.a_plane_stride = hs; g.a_ktiles = hkt; g.M = R;
     g.W = L.w_wo; g.KT = L.kt_wo; g.nstrips = L.ns_wo; g.epi = DIA_EPI_RESID_EMIT;
+    // cross-workgroup split-K measured SLOWER here (15.6 -> 20.7 us at batch 1: the release/ticket/acquire
+    // seam costs more than the shorter stream saves), so the engine keeps one workgroup per strip
+    g.sk = 1;
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D;
     g.gnext = (l + 1 < d.n_layer) ? e->layers[l + 1].g_sa : d.g_final;
     g.cmap = L.cmap_next;

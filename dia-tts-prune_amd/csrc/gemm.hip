@@ -58,6 +58,7 @@ struct GemmK {
   const float* cos_t; const float* sin_t;
   int spw;
   const int* cmap; const int* strip_map;
+  float* sk_scratch; int* sk_tickets;     // cross-workgroup split-K (gridDim.y > 1)
 };
 
 __device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v) {
@@ -182,6 +183,42 @@ __device__ __forceinline__ void reduce_to_tile(const f32x4* acc, f32x4* red, flo
   if constexpr (RAW) lds_barrier(); else __syncthreads();
 }
 
+// Cross-workgroup split-K: gridDim.y workgroups hold partial 16x16 tiles of one strip.  Each publishes
+// its tile to a slab; the LAST arriver (agent-scope release / ticket / acquire, guide §6 G16) sums the
+// slabs in split order — bit-reproducible regardless of arrival order — and alone runs the epilogue.
+// Returns true for the workgroup that must run the epilogue (always true when gridDim.y == 1).
+__device__ __forceinline__ bool splitk_combine(const GemmK& p, float* tile, int strip, int tid, int* flag_s) {
+  const int SK = gridDim.y;
+  if (SK == 1) return true;
+  const int ks = blockIdx.y;
+  float* slab = p.sk_scratch + ((long)strip * SK + ks) * 256;
+  if (tid < 256) slab[tid] = tile[(tid >> 4) * 17 + (tid & 15)];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(p.sk_tickets + strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == SK - 1;
+    if (last) {
+      __hip_atomic_store(p.sk_tickets + strip, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag_s = last;
+  }
+  __syncthreads();
+  if (!*flag_s) return false;
+  if (tid < 256) {
+    const float* base = p.sk_scratch + (long)strip * SK * 256 + tid;
+    float a = 0.f;
+    for (int k = 0; k < SK; ++k) a += base[k * 256];
+    tile[(tid >> 4) * 17 + (tid & 15)] = a;
+  }
+  __syncthreads();
+  return true;
+}
+
 template <int MT, int NW, int KPW>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -295,14 +332,16 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
   bf16x8* As = reinterpret_cast<bf16x8*>(smem_raw + sizeof(f32x4) * NW * 64 + sizeof(float) * (16 * 17 + 16));
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int kt0 = w * KPW;
+  const int kt0 = w * KPW;                 // k-tile inside this workgroup's K range
+  const int ktg = blockIdx.y * (NW * KPW); // first global k-tile of that range (split-K over gridDim.y)
   const int G = gridDim.x;                 // the workgroup walks strips blockIdx.x, +G, +2G, ...
-  const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + (long)kt0 * 64 + lane;
+  const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + (long)(ktg + kt0) * 64 + lane;
   auto load_strip = [&](bf16x8* b, int strip) {
     const bf16x8* Wt = Wl + (long)strip * p.KT * 64;
 #pragma unroll
     for (int i = 0; i < KPW; ++i) b[i] = DIA_WLOAD(Wt + (long)i * 64);
   };
+  __shared__ int sk_flag;
 
   STAMP(0);
   bf16x8 b0[KPW], b1[MULTI ? KPW : 1];
@@ -326,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
   for (int u = 0; u < CH; ++u) {
     const int c = min(tid + u * NT, nchunks - 1);
     const int row = c % RS, kq = (c / RS) & 3, kt = (c / (4 * RS)) % KT, pl = c / (4 * RS * KT);
-    v0[u] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)kt * 64 + row + 16 * kq) * 8);
+    v0[u] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)(ktg + kt) * 64 + row + 16 * kq) * 8);
   }
   // (2) strip sums of squares for the row scale: 8 threads per row, up to 16 strips each per round
   const bool has_norm = p.ssq_in != nullptr;
@@ -390,6 +429,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
     STAMP(3);
     reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
     STAMP(4);
+    if (!MULTI) { if (!splitk_combine(p, tile, strip, tid, &sk_flag)) return; }
     if (e_thread) {
       const int n0 = strip * 16 + half * 8;
       run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
@@ -421,8 +461,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
   constexpr int NT = NW * 64;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int kt0 = w * KPW;
+  const int kt0 = blockIdx.y * (NW * KPW) + w * KPW;      // split-K over gridDim.y
   const int G = gridDim.x;
+  __shared__ int sk_flag;
   const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + (long)kt0 * 64 + lane;
   auto load_strip = [&](bf16x8* b, int strip) {
     const bf16x8* Wt = Wl + (long)strip * p.KT * 64;
@@ -494,6 +535,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
       for (int pl = 0; pl < DIA_NPLANES; ++pl)
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], bc[i], acc[0], 0, 0, 0);
     reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
+    if (!MULTI) { if (!splitk_combine(p, tile, strip, tid, &sk_flag)) return; }
     if (e_thread) {
       const int n0 = strip * 16 + half * 8;
       run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
@@ -513,6 +555,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
 template <int NW, int KPW>
 int launch_g16(const GemmK& k, hipStream_t st) {
   const size_t smem = sizeof(f32x4) * NW * 64 + sizeof(float) * (16 * 17 + 16);
+  const int sk = k.KT / (NW * KPW);
+  if (sk > 1) {
+    launch_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
+    return dia_check_launch("k_gemm16");
+  }
   int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
   if (const char* e = getenv("DIA_DBG_SPW")) spw = atoi(e);
   if constexpr (!(NW == 16 && KPW >= 4)) {
@@ -526,9 +573,9 @@ int launch_g16(const GemmK& k, hipStream_t st) {
 }
 
 // returns true when a k_gemm16 instantiation exists for (nw, KT)
-int launch_g16_any(const GemmK& k, int nw, hipStream_t st, bool& handled) {
+int launch_g16_any(const GemmK& k, int nw, int sk, hipStream_t st, bool& handled) {
   handled = true;
-  const int kpw = (k.KT % nw == 0) ? k.KT / nw : 0;
+  const int kpw = (k.KT % (nw * sk) == 0) ? k.KT / (nw * sk) : 0;
   if (nw == 16) {
     if (kpw == 1) return launch_g16<16, 1>(k, st);
     if (kpw == 2) return launch_g16<16, 2>(k, st);
@@ -578,13 +625,13 @@ int launch_nw(const GemmK& k, int nw, int mgroups, hipStream_t st) {
   }
 }
 
-size_t small_smem(int nw, int KT, int rs) {
+size_t small_smem(int nw, int KT, int rs) {     // KT = k-tiles one workgroup stages (its own K range)
   return sizeof(f32x4) * nw * 64 + sizeof(float) * (16 * 17 + 16) + (size_t)DIA_NPLANES * KT * 4 * rs * 16;
 }
 
 template <int NW, int KPW, int RS>
 int launch_small(const GemmK& k, hipStream_t st) {
-  size_t smem = small_smem(NW, k.KT, RS);
+  size_t smem = small_smem(NW, NW * KPW, RS);
   if (const char* pad = getenv("DIA_DBG_LDS_PAD")) smem += (size_t)atoi(pad) * 1024;   // experiments: throttle residency
   if (smem > 64 * 1024) {
     int rc = dia_kernels_init_once();     // raises the dynamic-LDS limit of every large-LDS kernel, once
@@ -595,6 +642,11 @@ int launch_small(const GemmK& k, hipStream_t st) {
   int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
   if (const char* e = getenv("DIA_DBG_SPW")) spw = atoi(e);
   const int grid = (k.nstrips + spw - 1) / spw;
+  const int sk = k.KT / (NW * KPW);          // cross-workgroup split-K factor (1 = none)
+  if (sk > 1) {
+    launch_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
+    return dia_check_launch("k_gemv_small");
+  }
   if (spw > 1) {
     if constexpr (KPW <= 16 && !(NW == 16 && KPW > 4))
       launch_kernel(k_gemv_small<NW, KPW, RS, true>, dim3(grid), dim3(NW * 64), smem, st, k);
@@ -607,9 +659,9 @@ int launch_small(const GemmK& k, hipStream_t st) {
 }
 
 template <int RS>
-int launch_small_rs(const GemmK& k, int nw, hipStream_t st, bool& handled) {
+int launch_small_rs(const GemmK& k, int nw, int sk, hipStream_t st, bool& handled) {
   handled = true;
-  const int kpw = (k.KT % nw == 0) ? k.KT / nw : 0;
+  const int kpw = (k.KT % (nw * sk) == 0) ? k.KT / (nw * sk) : 0;
   if (nw == 4) {
     if (kpw == 4) return launch_small<4, 4, RS>(k, st);
     if (kpw == 8) return launch_small<4, 8, RS>(k, st);
@@ -633,12 +685,12 @@ int launch_small_rs(const GemmK& k, int nw, hipStream_t st, bool& handled) {
 template <int NW, int KPW>
 int small_attr() {
   hipError_t e[4];
-  e[0] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  e[1] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  e[0] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  e[1] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
   e[2] = e[3] = hipSuccess;
   if constexpr (KPW <= 16 && !(NW == 16 && KPW > 4)) {
-    e[2] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    e[3] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e[2] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    e[3] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
   }
   for (int i = 0; i < 4; ++i) if (e[i] != hipSuccess) return dia_fail_hip(e[i], "hipFuncSetAttribute(k_gemv_small)");
   return DIA_OK;
@@ -686,6 +738,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   k.kc = a->kc; k.vc = a->vc; k.kv_dtype = a->kv_dtype; k.kv_heads = a->kv_heads; k.kv_cap = a->kv_cap;
   k.kv_batch_index = a->kv_batch_index; k.cos_t = a->cos_t; k.sin_t = a->sin_t; k.spw = a->spw;
   k.cmap = a->cmap; k.strip_map = a->strip_map;
+  k.sk_scratch = a->sk_scratch; k.sk_tickets = a->sk_tickets;
 
   int nw = a->nw;
   if (nw == 0) {
@@ -700,25 +753,33 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   }
   const int mtiles = (a->M + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
+  // cross-workgroup split-K (opt-in, a->sk > 1): sk workgroups per strip, each 1/sk of K, combined by the
+  // last arriver.  Measured slower than one workgroup per strip on wo (the seam costs more than it saves).
+  int sk = 1;
+  if (a->sk > 1) sk = a->sk;
+  if (sk > 1 && (!a->sk_scratch || !a->sk_tickets || a->KT % sk != 0)) return dia_fail(DIA_E_ARG, "dia_gemm: split-K needs sk_scratch, sk_tickets and KT % sk == 0");
+  if (sk > 1 && !a->nw) { const int ktl = a->KT / sk; nw = (ktl % 16 == 0 && ktl / 16 <= 4) ? 16 : ((ktl % 8 == 0) ? 8 : 4); }
   if (a->M <= 4 && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext)) {
     const int rs = a->M <= 2 ? 2 : 4;
-    if (small_smem(nw, a->KT, rs) <= 150 * 1024) {
+    if (small_smem(nw, a->KT / sk, rs) <= 150 * 1024) {
       bool handled = false;
-      int rc = (rs == 2) ? launch_small_rs<2>(k, nw, st, handled) : launch_small_rs<4>(k, nw, st, handled);
+      int rc = (rs == 2) ? launch_small_rs<2>(k, nw, sk, st, handled) : launch_small_rs<4>(k, nw, sk, st, handled);
       if (handled) return rc;
     }
   }
   if (mtiles == 1 && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext)) {
     // registers hold the A fragments: 12*KPW VGPRs, so only short per-wave K ranges qualify
-    int nw16 = a->nw ? a->nw : ((a->KT % 16 == 0 && a->KT / 16 <= 4) ? 16 : ((a->KT % 8 == 0 && a->KT / 8 <= 8) ? 8 : 0));
+    const int ktl16 = a->KT / sk;
+    int nw16 = a->nw ? a->nw : ((ktl16 % 16 == 0 && ktl16 / 16 <= 4) ? 16 : ((ktl16 % 8 == 0 && ktl16 / 8 <= 8) ? 8 : 0));
     // the persistent multi-strip form double-buffers the weight tiles: 8 waves x 8 k-tiles fit, 16 x 4 spill
     if (!a->nw && a->nstrips >= 1024 && a->KT % 8 == 0 && a->KT / 8 <= 8) nw16 = 8;
     if (nw16) {
       bool handled = false;
-      int rc = launch_g16_any(k, nw16, st, handled);
+      int rc = launch_g16_any(k, nw16, sk, st, handled);
       if (handled) return rc;
     }
   }
+  if (sk > 1) return dia_fail(DIA_E_ARG, "dia_gemm: no split-K kernel for this shape");
   if (mtiles == 1) return launch_nw<1>(k, nw, 1, st);
   if (mtiles == 2) return launch_nw<2>(k, nw, 1, st);
   return launch_nw<4>(k, nw, (mtiles + 3) / 4, st);

@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("kc", C.c_void_p), ("vc", C.c_void_p), ("kv_dtype", C.c_int32), ("kv_heads", C.c_int32), ("kv_cap", C.c_int32),
         ("kv_batch_index", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("cmap", C.c_void_p), ("strip_map", C.c_void_p),
+        ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p), ("sk", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 
@@ -104,6 +105,7 @@ class EngineDesc(C.Structure):
         ("x", C.c_void_p), ("planes_x", C.c_void_p), ("planes_a", C.c_void_p), ("planes_h", C.c_void_p),
         ("ssq", C.c_void_p), ("qkv", C.c_void_p), ("qc", C.c_void_p), ("logits", C.c_void_p),
         ("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("text_len", C.c_void_p),
+        ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p),
         ("attn_scratch", C.c_void_p), ("attn_tickets", C.c_void_p),
         ("sample", SampleArgs),
     ]

@@ -231,6 +231,8 @@ class DecodeSession:
                   hb.lib().dia_attn_scratch_floats(B, d.cross_query_heads, self.S))
         self.attn_scratch = z(max(nsc, 1))
         self.attn_tickets = z(max(self.R * d.kv_heads, B * d.cross_query_heads), dt=torch.int32)
+        self.sk_scratch = z((self.D // 16) * 4 * 256)
+        self.sk_tickets = z(self.D // 16, dt=torch.int32)
 
         # token buffer + state machine (state.py:178-208; model.py:736-741)
         from .tokens import delayed_prefill
@@ -333,6 +335,7 @@ class DecodeSession:
         ed.ssq, ed.qkv, ed.qc, ed.logits = hb.ptr(self.ssq), hb.ptr(self.qkv), hb.ptr(self.qc), hb.ptr(self.logits)
         ed.cos_t, ed.sin_t, ed.text_len = hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(self.text_len)
         ed.attn_scratch, ed.attn_tickets = hb.ptr(self.attn_scratch), hb.ptr(self.attn_tickets)
+        ed.sk_scratch, ed.sk_tickets = hb.ptr(self.sk_scratch), hb.ptr(self.sk_tickets)
         ed.sample = self._sample_args()
         self._desc = ed
         hb.check(hb.lib().dia_engine_create(C.byref(ed), C.c_void_p(self.stream.cuda_stream), C.byref(self._engine)),

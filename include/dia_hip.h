@@ -95,6 +95,13 @@ typedef struct {
    *           of original strip strip_map[s] (whole heads dropped by a later o_proj). */
   const int32_t* cmap;
   const int32_t* strip_map;
+  /* cross-workgroup split-K (long K, few strips; one m-tile only): sk_scratch holds nstrips*sk*256 floats,
+   * sk_tickets nstrips int32 zeroed once by the caller (the kernel re-zeroes them).  sk: 0 or 1 = off,
+   * n > 1 = n workgroups per strip (opt-in: measured slower than 1 on the decode shapes). */
+  float* sk_scratch;
+  int32_t* sk_tickets;
+  int32_t sk;
+  int32_t _pad2;
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
@@ -245,6 +252,8 @@ typedef struct {
   const float* cos_t;       /* [T+1][64] */
   const float* sin_t;
   const int32_t* text_len;  /* [B] */
+  float* sk_scratch;        /* split-K slabs: (D/16)*4*256 floats */
+  int32_t* sk_tickets;      /* D/16 int32, zeroed by the caller once */
   float* attn_scratch;      /* max over self/cross of dia_attn_scratch_floats(...) floats */
   int32_t* attn_tickets;    /* max(R*kv_heads, B*cq_heads) int32, zeroed by the caller once */
   dia_sample_args sample;   /* sampler + FSM + embedding parameters */

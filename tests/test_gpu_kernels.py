@@ -24,7 +24,7 @@ def bf16r(t):
 
 
 def run_gemm(X, Wt, kt, ns, epi, *, akt=None, ssq_in=None, inv_d=0.0, eps=0.0, out=None, ldo=0, gnext=None, P=None,
-             p_kt=0, ssq_out=None, ssq_ld=0, kv=None, cos=None, sin=None, nw=0):
+             p_kt=0, ssq_out=None, ssq_ld=0, kv=None, cos=None, sin=None, nw=0, sk=None, reps=1):
     L = hb.lib()
     M = X.shape[0]
     A = lay.pack_planes(X, ktiles=akt)
@@ -41,8 +41,15 @@ def run_gemm(X, Wt, kt, ns, epi, *, akt=None, ssq_in=None, inv_d=0.0, eps=0.0, o
     if kv is not None:
         g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = kv
         g.cos_t, g.sin_t = hb.ptr(cos), hb.ptr(sin)
-    hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
+    if sk is not None:
+        scr = torch.zeros(ns * sk * 256, device=X.device)
+        tk = torch.zeros(ns, dtype=torch.int32, device=X.device)
+        g.sk_scratch, g.sk_tickets, g.sk = hb.ptr(scr), hb.ptr(tk), sk
+    for _ in range(reps):
+        hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
     torch.cuda.synchronize()
+    if sk is not None:
+        assert (tk == 0).all()                  # the last arriver re-arms the tickets
     return A
 
 
@@ -96,6 +103,29 @@ def test_gemm_resid_emit(M, K, D):
     assert torch.equal(lay.unpack_planes(P, M, D), x * gn)            # planes carry x*g exactly (3x bf16 == fp32)
     want = (x.double() ** 2).reshape(M, D // 16, 16).sum(-1).T
     assert (ssq[:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
+
+
+@pytest.mark.parametrize("M,K,D,sk", [(2, 8192, 2048, 4), (4, 8192, 512, 4), (16, 8192, 2048, 4), (9, 4096, 256, 2)])
+def test_gemm_split_k_resid(M, K, D, sk):
+    """cross-workgroup split-K (wo): partial tiles combined by the last arriver, fixed order"""
+    d = dev()
+    torch.manual_seed(K + D + M)
+    a = torch.randn(M, K, device=d)
+    W = bf16r(torch.randn(K, D, device=d) * 0.03)
+    x0 = torch.randn(M, D, device=d)
+    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+    Wt, kt, ns = lay.tile_weight(W)
+    outs = []
+    for _ in range(2):
+        x = x0.clone()
+        P = torch.zeros(3, 1, D // 32, 64, 8, dtype=torch.bfloat16, device=d)
+        ssq = torch.zeros(ns, 16, device=d)
+        run_gemm(a, Wt, kt, ns, hb.EPI_RESID_EMIT, out=x, ldo=D, gnext=gn, P=P, p_kt=D // 32, ssq_out=ssq, ssq_ld=16, sk=sk)
+        outs.append((x, P.clone(), ssq))
+    ref = x0.double() + a.double() @ W.double()
+    assert (outs[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # bit-reproducible
+    assert torch.equal(lay.unpack_planes(outs[0][1], M, D), outs[0][0] * gn)
 
 
 @pytest.mark.parametrize("M,K,F", [(2, 2048, 8192), (16, 256, 512), (33, 512, 1024)])
