@@ -73,13 +73,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N bench.py ...")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # rehearsal knob (1-GPU boxes): DIA_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and uses gloo,
+    # which exercises the whole N>1 code path except RCCL itself; never set by the driver
+    share = os.environ.get("DIA_BENCH_SHARE_DEVICE") == "1"
+    dev_index = 0 if share else local
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from dia_hip import config as C
     from dia_hip.engine import DecodeSession, DeviceWeights

@@ -261,3 +261,51 @@ def test_structured_pruned_checkpoint_is_compacted_and_matches_reference(mid, go
     for j, st in enumerate(g["logit_steps"]):
         err = float(np.abs(logits[int(st)][0] - g["logits"][j]).max())
         assert err <= LOGIT_TOL, (int(st), err)
+
+
+@pytest.mark.parametrize("temperature,top_p,top_k", [(0.0, 0.95, 35), (1.0, 1.0, 0), (0.8, 0.5, 0), (1.3, 0.95, 1)])
+def test_sampler_settings_free_running(mid, temperature, top_p, top_k):
+    """greedy, no top-k, no top-p, k=1: the device sampler + FSM against the oracle loop, free running"""
+    cfg, sd, w = mid
+    mt = 36
+    dm = O.Dims.of(cfg)
+    nz = O.exp_noise(5, mt - 1, dm.C, dm.tgt_vocab)
+    torch.set_num_threads(cpu_threads())
+    r = O.generate(sd, cfg, TEXTS[2], max_tokens=mt, noise=nz, mirror=False, temperature=temperature, top_p=top_p,
+                   cfg_filter_top_k=top_k, cfg_scale=2.0)
+    ids = [encode_text(effective_text(TEXTS[2]), cfg)]
+    s = DecodeSession(w, ids, kv_dtype="f32", max_tokens=mt, noise=nz[None], temperature=temperature, top_p=top_p,
+                      top_k=top_k, cfg_scale=2.0)
+    s.prefill(); s.run(use_graph=True, poll=64)
+    out = s.results()[0]; s.close()
+    assert np.array_equal(out.tokens, r.tokens)
+    assert out.last_step == r.last_step
+
+
+def test_edge_texts_and_full_length(mid):
+    """empty text (cross-attention sees no key: exact zeros like a fully masked row), text at the
+    encoder's maximum length (truncated like model.py:273-276), and a run to the very end of the
+    audio buffer (max_tokens == audio_length)."""
+    cfg, sd, w = mid
+    dm = O.Dims.of(cfg)
+    long_text = "[S1] " + "abcdefghij " * 40                       # > 256 bytes -> truncated to text_length
+    texts = ["", long_text]
+    mt = cfg.data.audio_length                                      # 256 for the mid config
+    runs = []
+    torch.set_num_threads(cpu_threads())
+    for i, t in enumerate(texts):
+        nz = O.exp_noise(11 + i, mt - 1, dm.C, dm.tgt_vocab)
+        runs.append((O.generate(sd, cfg, t, max_tokens=mt, noise=nz, mirror=False, ignore_eos=True, keep_logits=False), nz))
+    ids = [encode_text(effective_text(t), cfg) for t in texts]
+    assert len(ids[0]) == 0 and len(ids[1]) == cfg.data.text_length
+    s = DecodeSession(w, ids, kv_dtype="f32", max_tokens=mt, noise=torch.stack([nz for _, nz in runs]), ignore_eos=True)
+    s.prefill(); s.run(use_graph=True)
+    out = s.results(); s.close()
+    for b, (r, _) in enumerate(runs):
+        agree = (out[b].tokens == r.tokens).all(axis=1)
+        first_bad = int(np.argmin(agree)) if not agree.all() else mt
+        # 255 free-running steps: a near-tie may flip once in ~1e4-1e5 samples (SURVEY.md §7); require the
+        # first 64 rows exactly and report the rest
+        print(f"utterance {b}: free-running token rows identical up to row {first_bad} of {mt}")
+        assert first_bad >= 64
+        assert out[b].last_step == r.last_step == mt - 2
