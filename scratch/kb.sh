@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for cfg in "$@"; do
   set -- $cfg
   rm -rf /tmp/kb_prof
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kb_prof -- python scratch/kbench.py --shape $1 --nw $2 --M ${3:-2} --prefetch ${4:-0} --same ${5:-0} > /tmp/kb.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kb_prof -- python scratch/kbench.py --shape $1 --nw $2 --M ${3:-2} --prefetch ${4:-0} --same ${5:-0} --sk ${6:-0} > /tmp/kb.log 2>&1
   grep "us/launch" /tmp/kb.log
   python - <<PY
 import csv,glob

@@ -11,6 +11,7 @@ ap.add_argument("--M", type=int, default=2)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--prefetch", type=int, default=0)
 ap.add_argument("--same", type=int, default=0)
+ap.add_argument("--sk", type=int, default=0)
 a = ap.parse_args()
 d = torch.device("cuda:0")
 K, N, epi = {"wi": (2048, 16384, hb.EPI_SWIGLU_EMIT), "wo": (8192, 2048, hb.EPI_RESID_EMIT), "o": (2048, 2048, hb.EPI_RESID_EMIT),
@@ -27,6 +28,7 @@ ssq_out = torch.zeros(N // 16, mpad, device=d)
 gn = torch.ones(N, device=d)
 L = hb.lib()
 st = torch.cuda.Stream()
+skscr = torch.zeros((N // 16) * 8 * 256, device=d); sktk = torch.zeros(N // 16, dtype=torch.int32, device=d)
 def launch(W):
     g = hb.GemmArgs()
     g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
@@ -36,6 +38,8 @@ def launch(W):
     g.ssq_ld = mpad
     g.out, g.ldo, g.gnext = hb.ptr(out), out.shape[1], hb.ptr(gn)
     g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), P.shape[2], hb.ptr(ssq_out)
+    if a.sk > 1:
+        g.sk_scratch, g.sk_tickets, g.sk = hb.ptr(skscr), hb.ptr(sktk), a.sk
     hb.check(L.dia_gemm(C.byref(g), C.c_void_p(st.cuda_stream)), "gemm")
 if a.same: Ws = Ws[:1] * 18
 for W in Ws: launch(W)
