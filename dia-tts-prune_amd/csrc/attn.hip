@@ -39,7 +39,122 @@ struct AttnK {
   bf16_raw* P; long p_plane_stride; int p_ktiles;
   float* scratch; int* tickets; int max_chunks;
   const int* head_map;
+  int v_blocked;
 };
+
+#ifdef DIA_DBG_STAMPS
+__device__ long long g_astamps[8192 * 8];
+#define ASTAMP(i) do { if (threadIdx.x == 0) g_astamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ASTAMP(i) do {} while (0)
+#endif
+
+// Shared tail of both attention kernels: merge the NWV per-wave partials (LDS, fixed order), then —
+// when the pair was split over several workgroups — publish to the slab, take a ticket, and let the
+// last arriver merge all splits in split order; finally normalise and emit the planes.
+template <int G>
+__device__ __forceinline__ void attn_finish(const AttnK& p, const float* part, const float* pm_s, const float* pl_s,
+                                            int* last_s_ptr, int tid, int qrow, int kvh, int head_row, int chunk, int nchunks) {
+  int& last_s = *last_s_ptr;
+  // ---- G*16 threads own 8 output dims each ------------------------------------------------------------
+  const bool o_thread = tid < G * 16;
+  const int og = tid >> 4, od0 = (tid & 15) * 8;
+  float o[8];
+  float M = 0.f, Lsum = 1.f;
+  if (o_thread) {
+    float mm = -INFINITY;
+#pragma unroll
+    for (int ww = 0; ww < NWV; ++ww) mm = fmaxf(mm, pm_s[ww * 8 + og]);
+    float L2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NWV; ++ww) {
+      const float pmw = pm_s[ww * 8 + og];
+      const float f = (pmw == -INFINITY) ? 0.f : expf(pmw - mm);
+      L2 += pl_s[ww * 8 + og] * f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += part[(ww * G + og) * HD + od0 + j] * f;
+    }
+    M = mm; Lsum = L2;
+  }
+
+  if (nchunks > 1) {
+    // publish this chunk's slab, take a ticket; the last arriver merges
+    const long pair = (long)head_row * p.n_kv_heads + kvh;
+    float* slab = p.scratch + (pair * p.max_chunks + chunk) * SLAB;
+    if (o_thread) {
+      if ((tid & 15) == 0) { slab[og] = M; slab[8 + og] = Lsum; }
+      *reinterpret_cast<float4*>(slab + 16 + og * HD + od0) = float4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<float4*>(slab + 16 + og * HD + od0 + 4) = float4{o[4], o[5], o[6], o[7]};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(p.tickets + pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == nchunks - 1;
+      if (last) {
+        __hip_atomic_store(p.tickets + pair, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      last_s = last;
+    }
+    __syncthreads();
+    ASTAMP(5);
+    if (!last_s) return;
+    if (o_thread) {
+      const float* base = p.scratch + pair * p.max_chunks * SLAB;
+      constexpr int MAXC = 24;               // 3072 keys / 128
+      float mc[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) mc[c] = base[(long)min(c, nchunks - 1) * SLAB + og];   // independent loads
+      float mm = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) mm = fmaxf(mm, mc[c]);
+      for (int c = MAXC; c < nchunks; ++c) mm = fmaxf(mm, base[(long)c * SLAB + og]);        // capacity > 3072 only
+      float L2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
+      constexpr int MB = 12;                                         // slabs per round trip
+      for (int c0 = 0; c0 < nchunks; c0 += MB) {                    // chunk order: deterministic
+        float lc[MB], fm[MB]; float4 oa[MB], ob[MB];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+          const float* sl = base + (long)min(c0 + u, nchunks - 1) * SLAB;
+          fm[u] = sl[og]; lc[u] = sl[8 + og];
+          oa[u] = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0);
+          ob[u] = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+          const float f = (c0 + u < nchunks && fm[u] != -INFINITY) ? expf(fm[u] - mm) : 0.f;
+          L2 += lc[u] * f;
+          o[0] += oa[u].x * f; o[1] += oa[u].y * f; o[2] += oa[u].z * f; o[3] += oa[u].w * f;
+          o[4] += ob[u].x * f; o[5] += ob[u].y * f; o[6] += ob[u].z * f; o[7] += ob[u].w * f;
+        }
+      }
+      Lsum = L2;
+    }
+  }
+
+  if (o_thread) {
+    const float invl = Lsum > 0.f ? 1.0f / Lsum : 0.f;   // no keys (empty text) -> 0, like a fully masked row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] *= invl;
+    const int hpos = p.head_map ? p.head_map[kvh * G + og] : kvh * G + og;   // compacted o_proj input
+    const int col = hpos * HD + od0;
+    if (hpos >= 0) emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, qrow, col, o);
+    if (p.mode == DIA_ATTN_CROSS && hpos >= 0) {
+      // the uncond row's cross-attention mask is all False -> SDPA returns 0 (SURVEY.md App. B2)
+      const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, qrow - 1, col, z);
+    }
+  }
+  ASTAMP(6);
+}
 
 template <typename KVT, int G>
 __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
@@ -51,21 +166,20 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kvh = blockIdx.x, chunk = blockIdx.z;
-  int qrow, kvrow, pos, nkeys, slot = -1, head_row;
-  if (p.mode == DIA_ATTN_SELF) {
-    qrow = blockIdx.y; kvrow = qrow;
-    const int c = p.cur[qrow >> 1];
-    pos = c; nkeys = c; slot = c - 1;
-    head_row = qrow;
-  } else if (p.mode == DIA_ATTN_CROSS) {
-    const int b = blockIdx.y;
-    qrow = 2 * b + 1; kvrow = b;
-    pos = p.cur[b]; nkeys = p.len[b];
-    head_row = b;
-  } else {
-    qrow = blockIdx.y; kvrow = 0; pos = qrow; nkeys = p.enc_len;
-    head_row = qrow;
-  }
+  // mode decode, branch-free (cur/len are never null here: dia_attn substitutes a readable dummy):
+  //   SELF  row = grid y, kv row = row, position = cur[row/2], keys = cur, new slot = cur-1
+  //   CROSS utterance b = grid y, row = 2b+1 (cond), kv row = b, position = cur[b], keys = len[b]
+  //   ENC   row = grid y, kv row = 0, position = row, keys = enc_len
+  const int by = blockIdx.y;
+  const bool is_self = p.mode == DIA_ATTN_SELF, is_cross = p.mode == DIA_ATTN_CROSS;
+  const int c_cur = p.cur[is_self ? (by >> 1) : (is_cross ? by : 0)];
+  const int c_len = p.len[is_cross ? by : 0];
+  const int qrow = is_cross ? 2 * by + 1 : by;
+  const int kvrow = (is_self || is_cross) ? by : 0;
+  const int pos = (is_self || is_cross) ? c_cur : by;
+  const int nkeys = is_self ? c_cur : (is_cross ? c_len : p.enc_len);
+  const int slot = is_self ? c_cur - 1 : -1;
+  const int head_row = by;
   const int NZ = gridDim.z;
   const int nunits = max(1, (nkeys + UNIT - 1) / UNIT);
   if (chunk >= nunits) return;                        // uniform: nothing to do for this workgroup yet
@@ -224,101 +338,243 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
   }
   __syncthreads();
 
-  // ---- G*16 threads own 8 output dims each ------------------------------------------------------------
-  const bool o_thread = tid < G * 16;
-  const int og = tid >> 4, od0 = (tid & 15) * 8;
-  float o[8];
-  float M = 0.f, Lsum = 1.f;
-  if (o_thread) {
-    float mm = -INFINITY;
-#pragma unroll
-    for (int ww = 0; ww < NWV; ++ww) mm = fmaxf(mm, pm_s[ww * 8 + og]);
-    float L2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < NWV; ++ww) {
-      const float pmw = pm_s[ww * 8 + og];
-      const float f = (pmw == -INFINITY) ? 0.f : expf(pmw - mm);
-      L2 += pl_s[ww * 8 + og] * f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] += part[(ww * G + og) * HD + od0 + j] * f;
-    }
-    M = mm; Lsum = L2;
-  }
+  attn_finish<G>(p, part, pm_s, pl_s, &last_s, tid, qrow, kvh, head_row, chunk, nchunks);
+}
 
-  if (nchunks > 1) {
-    // publish this chunk's slab, take a ticket; the last arriver merges
-    const long pair = (long)head_row * p.n_kv_heads + kvh;
-    float* slab = p.scratch + (pair * p.max_chunks + chunk) * SLAB;
-    if (o_thread) {
-      if ((tid & 15) == 0) { slab[og] = M; slab[8 + og] = Lsum; }
-      *reinterpret_cast<float4*>(slab + 16 + og * HD + od0) = float4{o[0], o[1], o[2], o[3]};
-      *reinterpret_cast<float4*>(slab + 16 + og * HD + od0 + 4) = float4{o[4], o[5], o[6], o[7]};
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int ticket = __hip_atomic_fetch_add(p.tickets + pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = ticket == nchunks - 1;
-      if (last) {
-        __hip_atomic_store(p.tickets + pair, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      last_s = last;
-    }
-    __syncthreads();
-    if (!last_s) return;
-    if (o_thread) {
-      const float* base = p.scratch + pair * p.max_chunks * SLAB;
-      constexpr int MAXC = 24;               // 3072 keys / 128
-      float mc[MAXC];
-#pragma unroll
-      for (int c = 0; c < MAXC; ++c) mc[c] = base[(long)min(c, nchunks - 1) * SLAB + og];   // independent loads
-      float mm = -INFINITY;
-#pragma unroll
-      for (int c = 0; c < MAXC; ++c) mm = fmaxf(mm, mc[c]);
-      for (int c = MAXC; c < nchunks; ++c) mm = fmaxf(mm, base[(long)c * SLAB + og]);        // capacity > 3072 only
-      float L2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = 0.f;
-      for (int c0 = 0; c0 < nchunks; c0 += 8) {                     // chunk order: deterministic
-        float lc[8], fm[8]; float4 oa[8], ob[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float* sl = base + (long)min(c0 + u, nchunks - 1) * SLAB;
-          fm[u] = sl[og]; lc[u] = sl[8 + og];
-          oa[u] = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0);
-          ob[u] = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0 + 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float f = (c0 + u < nchunks && fm[u] != -INFINITY) ? expf(fm[u] - mm) : 0.f;
-          L2 += lc[u] * f;
-          o[0] += oa[u].x * f; o[1] += oa[u].y * f; o[2] += oa[u].z * f; o[3] += oa[u].w * f;
-          o[4] += ob[u].x * f; o[5] += ob[u].y * f; o[6] += ob[u].z * f; o[7] += ob[u].w * f;
-        }
-      }
-      Lsum = L2;
-    }
-  }
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+  return v;
+}
 
-  if (o_thread) {
-    const float invl = Lsum > 0.f ? 1.0f / Lsum : 0.f;   // no keys (empty text) -> 0, like a fully masked row
+// bf16 K/V caches, MFMA arithmetic.  Keys are dealt to WAVES in granules of 32: granule g goes to wave
+// g mod (4 * live workgroups), so the work is balanced to one granule whatever the length.  Per granule:
+//   S = Q.K^T   A = q as three bf16 planes (exact fp32 q), rows = query heads; B = K rows straight from the
+//               cache ([key][128], 16 B per lane: key l&15, dims 32*ks + 8*(l>>4)..); 2 key tiles x 4 k-steps x
+//               3 planes = 24 MFMAs into two 16x16 score tiles (lanes 0..15 = keys, registers = heads)
+//   online softmax on those tiles (row-of-16 DPP reductions), p written to LDS as hi+lo bf16 and read
+//               back in A-operand order (rows = heads, k = 32 keys)
+//   O += P.V    B = V from the BLOCKED cache layout [key/32][128 dims][32 keys] (16 B per lane: dim l&15 of
+//               dim block nb, keys 8*(l>>4)..): 8 dim blocks x 2 planes = 16 MFMAs
+// Latency plan (the kernel is a chain of dependent round trips, not a throughput problem): the q / new-k /
+// new-v loads do not depend on cur[] and are issued first; then cur -> cos/sin and the first granule's K/V
+// (vmcnt retires in order, so the small loads go ahead of the 16 KB granule); RoPE and the LDS hand-off run
+// under the K/V latency; the next granule is prefetched before the current one is consumed.  The wave that
+// owns the granule of the slot written this step appends k/v itself and patches its fragments from LDS
+// instead of waiting for its own store.  V of keys beyond the length is multiplied by p == 0 exactly:
+// the caches must hold finite values (the engine allocates them zeroed).
+#ifdef DIA_DBG_KV_NT
+#define KVLOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define KVLOAD(ptr) (*(ptr))
+#endif
+template <int G>
+struct MfmaFrag { bf16x8 kb[2][4]; bf16x8 vb[8]; };
+
+template <int G>
+__global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
+  __shared__ __attribute__((aligned(16))) bf16_raw qf[4][DIA_NPLANES][G][4][8];   // q planes in A-fragment order
+  __shared__ float part[NWV * G * HD];
+  __shared__ float pm_s[NWV * 8], pl_s[NWV * 8];
+  __shared__ __attribute__((aligned(16))) bf16_raw pbuf[NWV][2][16][32];
+  __shared__ __attribute__((aligned(16))) bf16_raw knew_s[HD], vnew_s[HD];
+  __shared__ int last_s;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kvh = blockIdx.x, chunk = blockIdx.z;
+  const int arow = lane & 15, akq = lane >> 4;
+  ASTAMP(0);
+  // SELF or CROSS only (see k_attn for the decode)
+  const int by = blockIdx.y;
+  const bool is_self = p.mode == DIA_ATTN_SELF;
+  const int qrow = is_self ? by : 2 * by + 1;
+  // ---- loads that do not need cur[]: this wave's q head (waves >= G re-read head G-1, branch-free) and
+  //      the new k / v of the kv head (CROSS: re-reads q, unused)
+  const float* qr = p.q + (long)qrow * p.ldq;
+  const float* qh = qr + p.q_off + (kvh * G + min(w, G - 1)) * HD;
+  const float* kh = qr + (is_self ? p.k_off : p.q_off) + kvh * HD;
+  const float* vh = qr + (is_self ? p.v_off : p.q_off) + kvh * HD;
+  const float qx1 = qh[lane], qx2 = qh[lane + 64];
+  const float kx1 = kh[lane], kx2 = kh[lane + 64];
+  const float vx1 = vh[lane], vx2 = vh[lane + 64];
+
+  const int c_cur = p.cur[is_self ? (by >> 1) : by];
+  const int c_len = p.len[is_self ? 0 : by];
+  const int kvrow = by, pos = c_cur;
+  const int nkeys = is_self ? c_cur : c_len;
+  const int slot = is_self ? c_cur - 1 : -1;
+  const int head_row = by;
+  const int NZ = gridDim.z;
+  const int ngran = (nkeys + 31) >> 5;
+  const int nchunks = min(NZ, max(1, (ngran + NWV - 1) / NWV));      // workgroups with at least one granule
+  if (chunk >= nchunks) return;
+  ASTAMP(1);
+  if (p.head_map) {
+    bool any_live = false;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] *= invl;
-    const int hpos = p.head_map ? p.head_map[kvh * G + og] : kvh * G + og;   // compacted o_proj input
-    const int col = hpos * HD + od0;
-    if (hpos >= 0) emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, qrow, col, o);
-    if (p.mode == DIA_ATTN_CROSS && hpos >= 0) {
-      // the uncond row's cross-attention mask is all False -> SDPA returns 0 (SURVEY.md App. B2)
-      const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, qrow - 1, col, z);
+    for (int g = 0; g < G; ++g) any_live |= p.head_map[kvh * G + g] >= 0;
+    if (!any_live && !is_self) return;
+  }
+  const float rc = p.cos_t[(long)pos * 64 + lane], rs = p.sin_t[(long)pos * 64 + lane];
+
+  bf16_raw* Kc = reinterpret_cast<bf16_raw*>(p.kc) + ((long)kvrow * p.n_kv_heads + kvh) * p.kv_cap * HD;
+  bf16_raw* Vc = reinterpret_cast<bf16_raw*>(p.vc) + ((long)kvrow * p.n_kv_heads + kvh) * p.kv_cap * HD;
+  const int klast = max(nkeys - 1, 0);
+  const int gstride = NWV * nchunks;
+  const int g_first = chunk * NWV + w;
+  auto load_gran = [&](MfmaFrag<G>& f, int gi) {
+    const int key0 = gi << 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#ifdef DIA_DBG_GRANMAJOR
+        f.kb[t][ks] = KVLOAD(reinterpret_cast<const bf16x8*>(reinterpret_cast<bf16_raw*>(p.kc) + (((long)gi * p.n_rows + kvrow) * p.n_kv_heads + kvh) * 4096 + (16 * t + arow) * HD + 32 * ks + 8 * akq));
+#else
+        f.kb[t][ks] = KVLOAD(reinterpret_cast<const bf16x8*>(Kc + (long)min(key0 + 16 * t + arow, klast) * HD + 32 * ks + 8 * akq));
+#endif
+#ifdef DIA_DBG_GRANMAJOR
+    const bf16_raw* Vblk = reinterpret_cast<bf16_raw*>(p.vc) + (((long)gi * p.n_rows + kvrow) * p.n_kv_heads + kvh) * 4096;
+#else
+    const bf16_raw* Vblk = Vc + (long)gi * HD * 32;
+#endif
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) f.vb[nb] = KVLOAD(reinterpret_cast<const bf16x8*>(Vblk + (long)(16 * nb + arow) * 32 + 8 * akq));
+  };
+  MfmaFrag<G> fa, fb;
+  const bool have0 = g_first < ngran;
+  load_gran(fa, have0 ? g_first : 0);          // idle waves re-read granule 0 (cache hit) and never use it
+
+  // ---- RoPE(q) -> LDS; the wave that owns the new slot's granule ropes k, appends k (row layout) and
+  //      v (blocked layout) and keeps a bf16 copy in LDS for its own fragments
+  if (w < G) {      // dim D of head w -> k-step D>>5, lane quarter (D>>3)&3, element D&7 of row w
+    const float qv[2] = {qx1 * rc - qx2 * rs, qx1 * rs + qx2 * rc};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int D = lane + 64 * e;
+      __bf16 a, b, c;
+      split3(qv[e], a, b, c);
+      qf[D >> 5][0][w][(D >> 3) & 3][D & 7] = *reinterpret_cast<const bf16_raw*>(&a);
+      qf[D >> 5][1][w][(D >> 3) & 3][D & 7] = *reinterpret_cast<const bf16_raw*>(&b);
+      qf[D >> 5][2][w][(D >> 3) & 3][D & 7] = *reinterpret_cast<const bf16_raw*>(&c);
     }
   }
+  const int gslot = slot >> 5;
+  const bool owner = slot >= 0 && (gslot % gstride) == g_first;      // wave-uniform
+  if (owner) {
+    const float k1 = kx1 * rc - kx2 * rs, k2 = kx1 * rs + kx2 * rc;
+    const __bf16 k1b = (__bf16)k1, k2b = (__bf16)k2, v1b = (__bf16)vx1, v2b = (__bf16)vx2;
+    const bf16_raw k1r = *reinterpret_cast<const bf16_raw*>(&k1b), k2r = *reinterpret_cast<const bf16_raw*>(&k2b);
+    const bf16_raw v1r = *reinterpret_cast<const bf16_raw*>(&v1b), v2r = *reinterpret_cast<const bf16_raw*>(&v2b);
+    knew_s[lane] = k1r; knew_s[lane + 64] = k2r; vnew_s[lane] = v1r; vnew_s[lane + 64] = v2r;
+    Kc[(long)slot * HD + lane] = k1r; Kc[(long)slot * HD + lane + 64] = k2r;
+    bf16_raw* vdst = Vc + (long)gslot * HD * 32 + (slot & 31);
+    vdst[(long)lane * 32] = v1r; vdst[(long)(lane + 64) * 32] = v2r;
+  }
+  lds_barrier();     // q (and the owner's k/v copy) in LDS; global loads stay in flight
+  ASTAMP(2);
+
+  // q fragments are re-read from LDS per k-step (rows >= G alias row G-1: their score rows are unused)
+  const int qrow_l = min(arow, G - 1);
+  const float scale = 0.08838834764831845f;
+  f32x4 O[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) O[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mrun[4], lrun[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { mrun[g] = -INFINITY; lrun[g] = 0.f; }
+
+  auto consume = [&](MfmaFrag<G>& f, int gi) {
+    const int key0 = gi << 5;
+    if (owner && gi == gslot) {                 // the slot written this step: fragments from the LDS copy
+      const int ts = (slot >> 4) & 1, ns = slot & 15, js = slot & 7, kqs = (slot & 31) >> 3;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kn = *reinterpret_cast<const bf16x8*>(&knew_s[32 * ks + 8 * akq]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          if (t == ts && arow == ns) f.kb[t][ks] = kn;
+      }
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        const bf16_raw vr = vnew_s[16 * nb + arow];
+        const __bf16 vn = *reinterpret_cast<const __bf16*>(&vr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j == js && akq == kqs) f.vb[nb][j] = vn;
+      }
+    }
+    f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&qf[ks][pl][qrow_l][akq][0]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, f.kb[t][ks], S[t], 0, 0, 0);
+      }
+    // online softmax: in lanes 0..15, S[t][g] is the score of head g against key key0 + 16t + lane
+    float alpha[4];
+    const bool v0 = key0 + arow < nkeys, v1 = key0 + 16 + arow < nkeys;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float s0 = v0 ? S[0][g] * scale : -INFINITY, s1 = v1 ? S[1][g] * scale : -INFINITY;
+      const float mnew = fmaxf(mrun[g], row16_max(fmaxf(s0, s1)));
+      alpha[g] = (mrun[g] == -INFINITY) ? 0.f : __expf(mrun[g] - mnew);
+      const float p0 = (s0 == -INFINITY) ? 0.f : __expf(s0 - mnew), p1 = (s1 == -INFINITY) ? 0.f : __expf(s1 - mnew);
+      lrun[g] = lrun[g] * alpha[g] + row16_sum(p0 + p1);
+      mrun[g] = mnew;
+      if (lane < 16) {      // p -> LDS as hi + lo bf16, [plane][head][key]
+        const __bf16 h0 = (__bf16)p0, h1 = (__bf16)p1;
+        const __bf16 l0 = (__bf16)(p0 - (float)h0), l1 = (__bf16)(p1 - (float)h1);
+        pbuf[w][0][g][lane] = *reinterpret_cast<const bf16_raw*>(&h0);
+        pbuf[w][0][g][16 + lane] = *reinterpret_cast<const bf16_raw*>(&h1);
+        pbuf[w][1][g][lane] = *reinterpret_cast<const bf16_raw*>(&l0);
+        pbuf[w][1][g][16 + lane] = *reinterpret_cast<const bf16_raw*>(&l1);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // rescale what is accumulated (register r of lanes 0..15 = head r)
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int g = 0; g < G; ++g) O[nb][g] *= alpha[g];
+    const bf16x8 pa0 = *reinterpret_cast<const bf16x8*>(&pbuf[w][0][arow][8 * akq]);
+    const bf16x8 pa1 = *reinterpret_cast<const bf16x8*>(&pbuf[w][1][arow][8 * akq]);
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      O[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa0, f.vb[nb], O[nb], 0, 0, 0);
+      O[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa1, f.vb[nb], O[nb], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();     // pbuf is rewritten by the next granule
+  };
+
+  // two granules per trip: the other register set is loading while one is consumed
+  for (int gi = g_first; gi < ngran; gi += 2 * gstride) {
+    const int g1 = gi + gstride, g2 = g1 + gstride;
+    if (g1 < ngran) load_gran(fb, g1);
+    consume(fa, gi);
+    if (g1 < ngran) {
+      if (g2 < ngran) load_gran(fa, g2);
+      consume(fb, g1);
+    }
+  }
+  ASTAMP(3);
+  // per-wave partial -> LDS (lanes 0..15: dim 16*nb + lane, register g = head)
+  if (lane < 16) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) part[(w * G + g) * HD + 16 * nb + lane] = O[nb][g];
+      if (lane == 0) { pm_s[w * 8 + g] = mrun[g]; pl_s[w * 8 + g] = lrun[g]; }
+    }
+  }
+  __syncthreads();
+  ASTAMP(4);
+  attn_finish<G>(p, part, pm_s, pl_s, &last_s, tid, qrow, kvh, head_row, chunk, nchunks);
 }
 
 __global__ void k_enc_kv_prep(const float* qkv, int ldq, int k_off, int v_off, int heads, int L, int cap,
@@ -343,7 +599,23 @@ int launch_attn(const AttnK& k, int grid_y, int grid_z, hipStream_t st) {
   return dia_check_launch("k_attn");
 }
 
+template <int G>
+int launch_attn_mfma(const AttnK& k, int grid_y, int grid_z, hipStream_t st) {
+  hipLaunchKernelGGL((k_attn_mfma<G>), dim3(k.n_kv_heads, grid_y, grid_z), dim3(NT), 0, st, k);
+  return dia_check_launch("k_attn_mfma");
+}
+
 }  // namespace
+
+#ifdef DIA_DBG_STAMPS
+extern "C" int dia_dbg_aclear() {
+  static long long zeros[8192 * 8];
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_astamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : -2;
+}
+extern "C" int dia_dbg_astamps(long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_astamps), sizeof(long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int dia_attn_init() { return DIA_OK; }   // static LDS only since the split-key rewrite
 
@@ -372,11 +644,24 @@ extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
   k.kc = a->kc; k.vc = a->vc; k.cur = a->cur; k.len = a->len; k.enc_len = a->enc_len;
   k.cos_t = a->cos_t; k.sin_t = a->sin_t;
   k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles;
-  k.head_map = a->head_map;
+  k.head_map = a->head_map; k.v_blocked = a->v_blocked;
+  // the kernels decode the mode branch-free and load cur[]/len[] unconditionally (index 0 when the mode
+  // does not use them): never hand them a null pointer
+  if (!k.cur) k.cur = reinterpret_cast<const int*>(a->cos_t);
+  if (!k.len) k.len = reinterpret_cast<const int*>(a->cos_t);
   k.scratch = a->scratch; k.tickets = a->tickets; k.max_chunks = (a->kv_cap + CHUNK - 1) / CHUNK;
   if ((a->n_kv_heads * a->group * 128 + 31) / 32 > a->p_ktiles) return dia_fail(DIA_E_ARG, "dia_attn: output planes too narrow");
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = a->kv_dtype == DIA_KV_F32;
+  if (a->v_blocked) {      // bf16 caches with the blocked V layout: MFMA kernel
+    if (f32 || a->mode == DIA_ATTN_ENC || a->kv_cap % 32 != 0) return dia_fail(DIA_E_ARG, "dia_attn: v_blocked needs bf16 K/V, SELF/CROSS mode and kv_cap % 32 == 0");
+    if (a->mode == DIA_ATTN_SELF && !a->cur) return dia_fail(DIA_E_ARG, "dia_attn: SELF needs cur");
+    if (a->mode == DIA_ATTN_CROSS && (!a->cur || !a->len || a->group != 1)) return dia_fail(DIA_E_ARG, "dia_attn: CROSS needs cur, len and group 1");
+    if (a->group == 4) return launch_attn_mfma<4>(k, a->n_rows, max_chunks, st);
+    if (a->group == 2) return launch_attn_mfma<2>(k, a->n_rows, max_chunks, st);
+    if (a->group == 1) return launch_attn_mfma<1>(k, a->n_rows, max_chunks, st);
+    return dia_fail(DIA_E_ARG, "dia_attn: GQA group must be 1, 2 or 4");
+  }
   switch (a->mode) {
     case DIA_ATTN_SELF:
       if (!a->cur) return dia_fail(DIA_E_ARG, "dia_attn: SELF needs cur");

@@ -41,7 +41,7 @@ class GemmArgs(C.Structure):
         ("kc", C.c_void_p), ("vc", C.c_void_p), ("kv_dtype", C.c_int32), ("kv_heads", C.c_int32), ("kv_cap", C.c_int32),
         ("kv_batch_index", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("cmap", C.c_void_p), ("strip_map", C.c_void_p),
-        ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p), ("sk", C.c_int32), ("_pad2", C.c_int32),
+        ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p), ("sk", C.c_int32), ("kv_vblocked", C.c_int32),
     ]
 
 
@@ -54,6 +54,7 @@ class AttnArgs(C.Structure):
         ("enc_len", C.c_int32), ("_pad0", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("_pad1", C.c_int32),
         ("scratch", C.c_void_p), ("tickets", C.c_void_p), ("head_map", C.c_void_p),
+        ("v_blocked", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 
@@ -99,7 +100,7 @@ class EngineDesc(C.Structure):
         ("n_layer", C.c_int32), ("D", C.c_int32), ("F", C.c_int32), ("q_heads", C.c_int32), ("kv_heads", C.c_int32),
         ("cq_heads", C.c_int32), ("C", C.c_int32), ("V", C.c_int32),
         ("B", C.c_int32), ("T", C.c_int32), ("S", C.c_int32), ("kv_dtype", C.c_int32),
-        ("rows_pad", C.c_int32), ("ld_logits", C.c_int32), ("eps", C.c_float), ("_pad0", C.c_int32),
+        ("rows_pad", C.c_int32), ("ld_logits", C.c_int32), ("eps", C.c_float), ("v_blocked", C.c_int32),
         ("layers", C.POINTER(DecLayer)), ("w_logits", C.c_void_p), ("kt_logits", C.c_int32), ("ns_logits", C.c_int32),
         ("g_final", C.c_void_p),
         ("x", C.c_void_p), ("planes_x", C.c_void_p), ("planes_a", C.c_void_p), ("planes_h", C.c_void_p),

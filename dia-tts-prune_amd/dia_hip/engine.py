@@ -197,10 +197,13 @@ class DecodeSession:
         if not (2 <= self.max_tokens <= self.T):
             raise ValueError(f"max_tokens must be in [2, {self.T}]")
         self.kv_code = {"f32": hb.KV_F32, "float32": hb.KV_F32, "bf16": hb.KV_BF16, "bfloat16": hb.KV_BF16}[kv_dtype]
+        import os as _os
+        # bf16 caches keep V blocked as [key/32][128][32] for the MFMA attention kernel
+        self.v_blocked = int(self.kv_code == hb.KV_BF16 and _os.environ.get("DIA_ATTN_VALU") != "1")
         kvt = torch.float32 if self.kv_code == hb.KV_F32 else torch.bfloat16
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.lens = [int(len(t)) for t in text_ids]
-        self.S = s_cap if s_cap is not None else max(16, _ceil(max(self.lens + [1]), 16))
+        self.S = s_cap if s_cap is not None else max(32, _ceil(max(self.lens + [1]), 32))
         if self.S > da.text_length and s_cap is None:
             self.S = da.text_length
         self.text_ids = [np.asarray(t, dtype=np.int32) for t in text_ids]
@@ -327,6 +330,7 @@ class DecodeSession:
         ed.q_heads, ed.kv_heads, ed.cq_heads = d.gqa_query_heads, d.kv_heads, d.cross_query_heads
         ed.C, ed.V, ed.B, ed.T, ed.S = self.C, self.V, self.B, self.T, self.S
         ed.kv_dtype, ed.rows_pad, ed.ld_logits = self.kv_code, self.rows_pad, self.ld_logits
+        ed.v_blocked = self.v_blocked
         ed.eps = float(self.cfg.model.normalization_layer_epsilon)
         ed.layers = C.cast(self._layers, C.POINTER(hb.DecLayer))
         ed.w_logits, ed.kt_logits, ed.ns_logits = hb.ptr(w.logits.t), w.logits.kt, w.logits.ns
@@ -401,6 +405,7 @@ class DecodeSession:
                         g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), p_kt
                     g.ssq_out = hb.ptr(ssq_out)
                     g.strip_map = hb.ptr(strip_map)
+                    g.kv_vblocked = self.v_blocked if kv is not None else 0
                     if kv is not None:
                         g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = kv
                         g.cos_t, g.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)

@@ -94,3 +94,15 @@ def rope_tables(npos: int, head_dim: int, min_ts: int, max_ts: int):
     pos = torch.arange(npos, dtype=torch.float32)
     f = pos.unsqueeze(-1) * inv_freq
     return torch.cos(f.to(torch.float32)).contiguous(), torch.sin(f.to(torch.float32)).contiguous()
+
+
+def v_to_blocked(v: torch.Tensor) -> torch.Tensor:
+    """V cache [..., T, 128] -> blocked [..., T/32, 128, 32] (the MFMA attention kernel's B operand wants
+    8 consecutive KEYS of one dim in 16 bytes); same number of elements, T % 32 == 0."""
+    *lead, T, H = v.shape
+    return v.reshape(*lead, T // 32, 32, H).transpose(-1, -2).contiguous()
+
+
+def v_from_blocked(vb: torch.Tensor) -> torch.Tensor:
+    *lead, nb, H, k = vb.shape
+    return vb.transpose(-1, -2).reshape(*lead, nb * k, H).contiguous()

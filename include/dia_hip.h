@@ -101,7 +101,7 @@ typedef struct {
   float* sk_scratch;
   int32_t* sk_tickets;
   int32_t sk;
-  int32_t _pad2;
+  int32_t kv_vblocked;      /* CROSSKV: 1 = write V in the blocked layout of dia_attn_args.v_blocked (kv_cap % 32 == 0) */
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
@@ -143,6 +143,10 @@ typedef struct {
   /* int32 [n_kv_heads*group] or NULL: query head h is emitted at head position head_map[h] of the
    * (compacted) o_proj input; < 0 = head pruned, nothing emitted */
   const int32_t* head_map;
+  /* 1: bf16 caches with V stored blocked as [key/32][128 dims][32 keys] (K stays [key][128]) -> the MFMA
+   * attention kernel; 0: V stored [key][128] -> the VALU kernel (required for fp32 caches and ENC) */
+  int32_t v_blocked;
+  int32_t _pad2;
 } dia_attn_args;
 int dia_attn(const dia_attn_args* a, void* stream);
 int dia_attn_scratch_floats(int n_rows, int n_kv_heads, int kv_cap);
@@ -235,7 +239,7 @@ typedef struct {
   int32_t rows_pad;         /* 16 * ceil(R/16) */
   int32_t ld_logits;        /* 16 * ceil(C*V/16) */
   float eps;
-  int32_t _pad0;
+  int32_t v_blocked;        /* 1: V caches in the blocked layout (bf16 only) -> MFMA attention */
   const dia_dec_layer* layers;   /* host array [n_layer] */
   const void* w_logits;
   int32_t kt_logits, ns_logits;

@@ -24,7 +24,7 @@ def bf16r(t):
 
 
 def run_gemm(X, Wt, kt, ns, epi, *, akt=None, ssq_in=None, inv_d=0.0, eps=0.0, out=None, ldo=0, gnext=None, P=None,
-             p_kt=0, ssq_out=None, ssq_ld=0, kv=None, cos=None, sin=None, nw=0, sk=None, reps=1):
+             p_kt=0, ssq_out=None, ssq_ld=0, kv=None, cos=None, sin=None, nw=0, sk=None, reps=1, kv_vblocked=0):
     L = hb.lib()
     M = X.shape[0]
     A = lay.pack_planes(X, ktiles=akt)
@@ -41,6 +41,7 @@ def run_gemm(X, Wt, kt, ns, epi, *, akt=None, ssq_in=None, inv_d=0.0, eps=0.0, o
     if kv is not None:
         g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = kv
         g.cos_t, g.sin_t = hb.ptr(cos), hb.ptr(sin)
+        g.kv_vblocked = kv_vblocked
     if sk is not None:
         scr = torch.zeros(ns * sk * 256, device=X.device)
         tk = torch.zeros(ns, dtype=torch.int32, device=X.device)
@@ -165,8 +166,15 @@ def test_gemm_crosskv(kvd):
     vc = torch.zeros(2, H, cap, 128, dtype=kdt, device=d)
     mpad = (Lq + 15) // 16 * 16
     code = hb.KV_F32 if kvd == "f32" else hb.KV_BF16
+    blocked = kvd == "bf16"
+    if blocked:
+        cap = 64
+        kc = torch.zeros(2, H, cap, 128, dtype=kdt, device=d)
+        vc = torch.zeros(2, H, cap, 128, dtype=kdt, device=d)
     run_gemm(x * gw, Wt, kt, ns, hb.EPI_CROSSKV, ssq_in=strip_ssq(x, mpad), inv_d=1.0 / E, eps=1e-5, ssq_ld=mpad,
-             kv=(hb.ptr(kc), hb.ptr(vc), code, H, cap, 1), cos=cos, sin=sin)
+             kv=(hb.ptr(kc), hb.ptr(vc), code, H, cap, 1), cos=cos, sin=sin, kv_vblocked=int(blocked))
+    if blocked:
+        vc = lay.v_from_blocked(vc.reshape(2, H, cap // 32, 128, 32))
     xd = x.double()
     h = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
     k = torch.einsum("me,ehd->mhd", h, wk.double())
@@ -187,8 +195,13 @@ def attn_ref(q, K, V):
 
 
 @pytest.mark.parametrize("kvd", ["f32", "bf16"])
-@pytest.mark.parametrize("B,cur", [(1, 1), (1, 37), (1, 128), (1, 129), (2, 300), (1, 1025), (1, 1280)])
-def test_attn_self(kvd, B, cur):
+@pytest.mark.parametrize("B,cur,nz", [(1, 1, 0), (1, 37, 0), (1, 128, 0), (1, 129, 0), (2, 300, 0), (1, 1025, 0), (1, 1280, 0),
+                                      (1, 1025, 1), (2, 300, 2), (1, 1280, 3), (1, 640, 2)])
+def test_attn_self(kvd, B, cur, nz, monkeypatch):
+    """nz > 0 forces the key-split factor: few workgroups -> several rounds per wave (prefetch path, the
+    new slot in a later round), many -> one granule per wave."""
+    if nz:
+        monkeypatch.setenv("DIA_DBG_NZ", str(nz))
     d = dev()
     torch.manual_seed(cur)
     R, QH, KVH, T = 2 * B, 16, 4, 1280
@@ -197,6 +210,9 @@ def test_attn_self(kvd, B, cur):
     kdt = torch.float32 if kvd == "f32" else torch.bfloat16
     kc = (torch.randn(R, KVH, T, 128, device=d)).to(kdt)
     vc = (torch.randn(R, KVH, T, 128, device=d)).to(kdt)
+    blocked = kvd == "bf16"                       # bf16 caches: V blocked, MFMA kernel
+    if blocked:
+        vc = lay.v_to_blocked(vc)
     kc0, vc0 = kc.clone(), vc.clone()
     cos, sin = [t.to(d) for t in lay.rope_tables(T + 1, 128, 1, 10000)]
     curs = torch.full((B,), cur, dtype=torch.int32, device=d)
@@ -211,11 +227,14 @@ def test_attn_self(kvd, B, cur):
     scr = torch.zeros(hb.lib().dia_attn_scratch_floats(R, KVH, T), device=d)
     tk = torch.zeros(R * KVH, dtype=torch.int32, device=d)
     a.scratch, a.tickets = hb.ptr(scr), hb.ptr(tk)
+    a.v_blocked = int(blocked)
     for _ in range(2):                                  # second launch: tickets were re-zeroed by the kernel
         kc.copy_(kc0); vc.copy_(vc0)
         hb.check(hb.lib().dia_attn(C.byref(a), None), "dia_attn")
     torch.cuda.synchronize()
     assert (tk == 0).all()
+    if blocked:
+        vc, vc0 = lay.v_from_blocked(vc), lay.v_from_blocked(vc0)
     out = lay.unpack_planes(P, R, QH * 128).double().reshape(R, QH, 128)
 
     def rope(x, pos):
@@ -246,8 +265,8 @@ def test_attn_self(kvd, B, cur):
 def test_attn_cross_and_uncond_zero(kvd):
     d = dev()
     torch.manual_seed(11)
-    B, H, S = 3, 16, 208
-    lens = [75, 208, 0]
+    B, H, S = 3, 16, 224
+    lens = [75, 224, 0]
     R = 2 * B
     qc = torch.randn(R, H * 128, device=d)
     kdt = torch.float32 if kvd == "f32" else torch.bfloat16
@@ -266,8 +285,12 @@ def test_attn_cross_and_uncond_zero(kvd):
     scr = torch.zeros(hb.lib().dia_attn_scratch_floats(B, H, S), device=d)
     tk = torch.zeros(B * H, dtype=torch.int32, device=d)
     a.scratch, a.tickets = hb.ptr(scr), hb.ptr(tk)
+    vc_row = vc
+    if kvd == "bf16":
+        vc = lay.v_to_blocked(vc); a.vc = hb.ptr(vc); a.v_blocked = 1
     hb.check(hb.lib().dia_attn(C.byref(a), None), "dia_attn")
     torch.cuda.synchronize()
+    vc = vc_row
     out = lay.unpack_planes(P, R, H * 128).double().reshape(R, H, 128)
     for b in range(B):
         assert (out[2 * b] == 0).all()                      # uncond row: fully masked -> exactly 0
