@@ -80,26 +80,24 @@ __device__ __forceinline__ void attn_finish(const AttnK& p, const float* part, c
   }
 
   if (nchunks > 1) {
-    // publish this chunk's slab, take a ticket; the last arriver merges
+    // Publish this chunk's slab, take a ticket; the last arriver merges.  The hand-off uses agent-scope
+    // RELAXED atomics (sc1 stores/loads: written through to / read from the device coherence point) with the
+    // ordering made explicit — stores acknowledged (vmcnt 0) before the ticket is taken, slab loads issued
+    // after the ticket came back — instead of release/acquire fences: on gfx950 those are a whole-L2
+    // write-back (buffer_wbl2) and invalidate (buffer_inv) per workgroup, microseconds under load.
     const long pair = (long)head_row * p.n_kv_heads + kvh;
     float* slab = p.scratch + (pair * p.max_chunks + chunk) * SLAB;
     if (o_thread) {
-      if ((tid & 15) == 0) { slab[og] = M; slab[8 + og] = Lsum; }
-      *reinterpret_cast<float4*>(slab + 16 + og * HD + od0) = float4{o[0], o[1], o[2], o[3]};
-      *reinterpret_cast<float4*>(slab + 16 + og * HD + od0 + 4) = float4{o[4], o[5], o[6], o[7]};
+      if ((tid & 15) == 0) st2_agent(slab + 2 * og, M, Lsum);
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) st2_agent(slab + 16 + og * HD + od0 + j, o[j], o[j + 1]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int ticket = __hip_atomic_fetch_add(p.tickets + pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = ticket == nchunks - 1;
-      if (last) {
-        __hip_atomic_store(p.tickets + pair, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (last) __hip_atomic_store(p.tickets + pair, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       last_s = last;
     }
     __syncthreads();
@@ -108,32 +106,40 @@ __device__ __forceinline__ void attn_finish(const AttnK& p, const float* part, c
     if (o_thread) {
       const float* base = p.scratch + pair * p.max_chunks * SLAB;
       constexpr int MAXC = 24;               // 3072 keys / 128
-      float mc[MAXC];
+      float mc[MAXC], lcs[MAXC];
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) mc[c] = base[(long)min(c, nchunks - 1) * SLAB + og];   // independent loads
+      for (int c = 0; c < MAXC; ++c) {       // independent loads
+        const float2 ml = ld2_agent(base + (long)min(c, nchunks - 1) * SLAB + 2 * og);
+        mc[c] = ml.x; lcs[c] = ml.y;
+      }
+      constexpr int MB = 12;                 // slabs per round trip
       float mm = -INFINITY;
-#pragma unroll
-      for (int c = 0; c < MAXC; ++c) mm = fmaxf(mm, mc[c]);
-      for (int c = MAXC; c < nchunks; ++c) mm = fmaxf(mm, base[(long)c * SLAB + og]);        // capacity > 3072 only
       float L2 = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = 0.f;
-      constexpr int MB = 12;                                         // slabs per round trip
       for (int c0 = 0; c0 < nchunks; c0 += MB) {                    // chunk order: deterministic
-        float lc[MB], fm[MB]; float4 oa[MB], ob[MB];
+        float2 ov[MB][4];
 #pragma unroll
         for (int u = 0; u < MB; ++u) {
-          const float* sl = base + (long)min(c0 + u, nchunks - 1) * SLAB;
-          fm[u] = sl[og]; lc[u] = sl[8 + og];
-          oa[u] = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0);
-          ob[u] = *reinterpret_cast<const float4*>(sl + 16 + og * HD + od0 + 4);
+          const float* sl = base + (long)min(c0 + u, nchunks - 1) * SLAB + 16 + og * HD + od0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ov[u][j] = ld2_agent(sl + 2 * j);
+        }
+        if (c0 == 0) {
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c) mm = fmaxf(mm, mc[c]);
+          for (int c = MAXC; c < nchunks; ++c) mm = fmaxf(mm, ld2_agent(base + (long)c * SLAB + 2 * og).x);   // capacity > 3072 only
         }
 #pragma unroll
         for (int u = 0; u < MB; ++u) {
-          const float f = (c0 + u < nchunks && fm[u] != -INFINITY) ? expf(fm[u] - mm) : 0.f;
-          L2 += lc[u] * f;
-          o[0] += oa[u].x * f; o[1] += oa[u].y * f; o[2] += oa[u].z * f; o[3] += oa[u].w * f;
-          o[4] += ob[u].x * f; o[5] += ob[u].y * f; o[6] += ob[u].z * f; o[7] += ob[u].w * f;
+          const int c = c0 + u;
+          float mcu, lcu;
+          if (c0 == 0) { mcu = mc[u]; lcu = lcs[u]; }               // (u < MB <= MAXC)
+          else { const float2 ml = ld2_agent(base + (long)min(c, nchunks - 1) * SLAB + 2 * og); mcu = ml.x; lcu = ml.y; }
+          const float f = (c < nchunks && mcu != -INFINITY) ? expf(mcu - mm) : 0.f;
+          L2 += lcu * f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { o[2 * j] += ov[u][j].x * f; o[2 * j + 1] += ov[u][j].y * f; }
         }
       }
       Lsum = L2;

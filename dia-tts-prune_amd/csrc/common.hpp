@@ -66,6 +66,17 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Device-coherent 8-byte accesses (agent-scope relaxed atomics = sc1 global_store/load_dwordx2): written
+// through to / read from the point where all XCDs agree, without any cache-wide fence.
+__device__ __forceinline__ void st2_agent(float* p, float a, float b) {
+  const unsigned long long v = ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld2_agent(const float* p) {
+  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return float2{__uint_as_float((unsigned)(v & 0xffffffffull)), __uint_as_float((unsigned)(v >> 32))};
+}
+
 // compacted consumers: column n0+j goes to plane position cmap[n0+j] (2-byte stores), or nowhere
 __device__ __forceinline__ void emit_planes8_mapped(bf16_raw* P, long plane_stride, int ktiles, int m, int n0,
                                                     const float* v, const int* cmap) {

@@ -199,29 +199,29 @@ __device__ __forceinline__ bool splitk_combine(const GemmK& p, float* tile, int 
   const int SK = gridDim.y;
   if (SK == 1) return true;
   const int ks = blockIdx.y;
+  // hand-off through device-coherent (sc1) accesses with explicit ordering, no cache-wide fences — see
+  // attn_finish in attn.hip
   float* slab = p.sk_scratch + ((long)strip * SK + ks) * 256;
-  if (tid < 256) slab[tid] = tile[(tid >> 4) * 17 + (tid & 15)];
+  if (tid < 128) {
+    const int e = tid * 2;
+    st2_agent(slab + e, tile[(e >> 4) * 17 + (e & 15)], tile[(e >> 4) * 17 + (e & 15) + 1]);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int ticket = __hip_atomic_fetch_add(p.sk_tickets + strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == SK - 1;
-    if (last) {
-      __hip_atomic_store(p.sk_tickets + strip, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (last) __hip_atomic_store(p.sk_tickets + strip, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     *flag_s = last;
   }
   __syncthreads();
   if (!*flag_s) return false;
-  if (tid < 256) {
-    const float* base = p.sk_scratch + (long)strip * SK * 256 + tid;
-    float a = 0.f;
-    for (int k = 0; k < SK; ++k) a += base[k * 256];
-    tile[(tid >> 4) * 17 + (tid & 15)] = a;
+  if (tid < 128) {
+    const int e = tid * 2;
+    const float* base = p.sk_scratch + (long)strip * SK * 256 + e;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < SK; ++k) { const float2 v = ld2_agent(base + k * 256); a += v.x; b += v.y; }
+    tile[(e >> 4) * 17 + (e & 15)] = a; tile[(e >> 4) * 17 + (e & 15) + 1] = b;
   }
   __syncthreads();
   return true;
