@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 #include <utility>
@@ -128,14 +129,20 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g = {};
     g.A = d.planes_h; g.a_plane_stride = hs; g.a_ktiles = hkt; g.M = R;
     g.W = L.w_wo; g.KT = L.kt_wo; g.nstrips = L.ns_wo; g.epi = DIA_EPI_RESID_EMIT;
-    // cross-workgroup split-K measured SLOWER here (15.6 -> 20.7 us at batch 1: the release/ticket/acquire
-    // seam costs more than the shorter stream saves), so the engine keeps one workgroup per strip
-    g.sk = 1;
+    // K = 8192 over only D/16 = 128 strips: at M <= 4 two workgroups per strip (cross-workgroup split-K,
+    // fence-free slab hand-off) stream the matrix from twice as many CUs: 12.4 -> 11.2 us per launch.
+    // More splits or more rows lose again to the seam; shapes without a split kernel fall back to one.
+    int wo_sk = (R <= 4 && L.kt_wo % 2 == 0) ? 2 : 1;
+    if (const char* ev = getenv("DIA_DBG_WO_SK")) wo_sk = atoi(ev) >= 1 && atoi(ev) <= 4 ? atoi(ev) : wo_sk;
+    g.sk = wo_sk; g.sk_scratch = wo_sk > 1 ? d.sk_scratch : nullptr; g.sk_tickets = wo_sk > 1 ? d.sk_tickets : nullptr;
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D;
     g.gnext = (l + 1 < d.n_layer) ? e->layers[l + 1].g_sa : d.g_final;
     g.cmap = L.cmap_next;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
-    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
+    rc = dia_gemm(&g, st);
+    if (rc == DIA_E_ARG && g.sk > 1) { g.sk = 1; g.sk_scratch = nullptr; g.sk_tickets = nullptr; rc = dia_gemm(&g, st); }
+    if (rc) return rc;
+    mark(e, n++);
   }
   // final norm + logits (layers.py:714-717)
   dia_gemm_args g = {};
