@@ -590,7 +590,11 @@ int launch_g16_any(const GemmK& k, int nw, int sk, hipStream_t st, bool& handled
     if (kpw == 4) return launch_g16<16, 4>(k, st);
   } else if (nw == 8) {
     if (kpw == 2) return launch_g16<8, 2>(k, st);
+    if (kpw == 3) return launch_g16<8, 3>(k, st);
     if (kpw == 4) return launch_g16<8, 4>(k, st);
+    if (kpw == 5) return launch_g16<8, 5>(k, st);
+    if (kpw == 6) return launch_g16<8, 6>(k, st);
+    if (kpw == 7) return launch_g16<8, 7>(k, st);
     if (kpw == 8) return launch_g16<8, 8>(k, st);
   } else if (nw == 4) {
     if (kpw == 4) return launch_g16<4, 4>(k, st);
@@ -676,7 +680,11 @@ int launch_small_rs(const GemmK& k, int nw, int sk, hipStream_t st, bool& handle
     if (kpw == 16) return launch_small<4, 16, RS>(k, st);
   } else if (nw == 8) {
     if (kpw == 2) return launch_small<8, 2, RS>(k, st);
+    if (kpw == 3) return launch_small<8, 3, RS>(k, st);      // 3, 5, 6, 7: K-compacted (pruned) shapes, K % 256 == 0
     if (kpw == 4) return launch_small<8, 4, RS>(k, st);
+    if (kpw == 5) return launch_small<8, 5, RS>(k, st);
+    if (kpw == 6) return launch_small<8, 6, RS>(k, st);
+    if (kpw == 7) return launch_small<8, 7, RS>(k, st);
     if (kpw == 8) return launch_small<8, 8, RS>(k, st);
     if (kpw == 16) return launch_small<8, 16, RS>(k, st);
     if (kpw == 32) return launch_small<8, 32, RS>(k, st);
@@ -716,7 +724,7 @@ extern "C" int dia_dbg_stamps(long long* host, int n) {
 int dia_gemm_init() {
   int rc = 0;
   rc |= small_attr<4, 4>(); rc |= small_attr<4, 8>(); rc |= small_attr<4, 16>();
-  rc |= small_attr<8, 2>(); rc |= small_attr<8, 4>(); rc |= small_attr<8, 8>(); rc |= small_attr<8, 16>(); rc |= small_attr<8, 32>();
+  rc |= small_attr<8, 2>(); rc |= small_attr<8, 3>(); rc |= small_attr<8, 4>(); rc |= small_attr<8, 5>(); rc |= small_attr<8, 6>(); rc |= small_attr<8, 7>(); rc |= small_attr<8, 8>(); rc |= small_attr<8, 16>(); rc |= small_attr<8, 32>();
   rc |= small_attr<16, 1>(); rc |= small_attr<16, 2>(); rc |= small_attr<16, 4>(); rc |= small_attr<16, 8>();
   return rc ? DIA_E_HIP : DIA_OK;
 }

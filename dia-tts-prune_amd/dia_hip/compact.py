@@ -36,6 +36,29 @@ def _cmap(keep: torch.Tensor) -> torch.Tensor:
     return torch.where(keep, idx, torch.full_like(idx, -1)).to(torch.int32)
 
 
+K_GRANULE = 256      # rows: 8 k-tiles of 32, the per-wave K split of the 8-wave GEMV kernels
+
+
+def _granule(n: int) -> int:
+    """full-size matrices (K >= 2048): whole per-wave k-tile groups; smaller test models: whole k-tiles"""
+    return K_GRANULE if n >= 2048 and n % K_GRANULE == 0 else 32
+
+
+def pad_keep(keep: torch.Tensor, granule: int = 0) -> torch.Tensor:
+    """bool [D] -> bool [D] with the kept count rounded up to a multiple of `granule` by re-adding the
+    first dropped rows.  Those rows are zero in the checkpoint, so they change nothing but the shape: the
+    fast kernels want K in whole per-wave k-tile groups (a union of q/k/v keep sets is ~1792 of 2048)."""
+    granule = granule or _granule(keep.numel())
+    n = int(keep.sum())
+    pad = (-n) % granule
+    if pad == 0 or keep.numel() % granule != 0:
+        return keep
+    dropped = torch.nonzero(~keep).flatten()[:pad]
+    out = keep.clone()
+    out[dropped] = True
+    return out
+
+
 @dataclass
 class LayerPlan:
     keep_qkv: torch.Tensor            # bool [D]  union of q/k/v input rows
@@ -58,7 +81,7 @@ def plan_decoder_layer(sd: Dict[str, torch.Tensor], prefix: str, q_heads: int, k
     live_kv = live_q.reshape(kv_heads, grp).any(dim=1)
     live_c = nonzero_rows(g("cross_attention.o_proj.weight").reshape(cq_heads, -1))
     keep_ckv = rows("cross_attention.k_proj.weight") | rows("cross_attention.v_proj.weight")
-    return LayerPlan(keep_qkv, rows("cross_attention.q_proj.weight"), rows("mlp.wi_fused.weight"),
+    return LayerPlan(pad_keep(keep_qkv), pad_keep(rows("cross_attention.q_proj.weight")), pad_keep(rows("mlp.wi_fused.weight")),
                      live_q, live_kv, live_c, rows("mlp.wo.weight"), keep_ckv)
 
 
@@ -81,9 +104,11 @@ def strips_of_heads(live_heads: torch.Tensor, head_offset_cols: int = 0) -> List
 
 
 def pad_hidden_keep(live_hidden: torch.Tensor) -> torch.Tensor:
-    """indices of the live hidden units (int64), their count padded up to a multiple of 8 with -1"""
+    """indices of the live hidden units (int64), their count padded up to a multiple of K_GRANULE (8 for toy sizes) with -1
+    (zero gate/up columns in wi, zero rows in wo)"""
     idx = torch.nonzero(live_hidden).flatten()
-    pad = (-idx.numel()) % 8
+    granule = K_GRANULE if (live_hidden.numel() >= 2048 and live_hidden.numel() % K_GRANULE == 0) else 8   # small models: whole strips only
+    pad = (-idx.numel()) % granule
     if pad:
         idx = torch.cat([idx, torch.full((pad,), -1, dtype=idx.dtype, device=idx.device)])
     return idx

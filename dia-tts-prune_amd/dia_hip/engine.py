@@ -86,7 +86,7 @@ class DeviceWeights:
             pl = cpt.plan_decoder_layer({k: v for k, v in sd.items() if k.startswith(f"decoder.layers.{i}.")},
                                         f"decoder.layers.{i}.", QH, KVH, CH)
             plans.append(pl if (compact != "off" and cpt.is_pruned(pl)) else None)
-        keep_logits = cpt.nonzero_rows(sd["decoder.logits_dense.weight"].reshape(D, -1))
+        keep_logits = cpt.pad_keep(cpt.nonzero_rows(sd["decoder.logits_dense.weight"].reshape(D, -1)))
         logits_pruned = compact != "off" and not bool(keep_logits.all())
         self.compacted = any(p is not None for p in plans) or logits_pruned
         i32 = lambda t: t.to(device=device, dtype=torch.int32).contiguous()

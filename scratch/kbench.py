@@ -15,7 +15,8 @@ ap.add_argument("--sk", type=int, default=0)
 a = ap.parse_args()
 d = torch.device("cuda:0")
 K, N, epi = {"wi": (2048, 16384, hb.EPI_SWIGLU_EMIT), "wo": (8192, 2048, hb.EPI_RESID_EMIT), "o": (2048, 2048, hb.EPI_RESID_EMIT),
-             "qkv": (2048, 3072, hb.EPI_SCALE_STORE), "logits": (2048, 9264, hb.EPI_SCALE_STORE)}[a.shape]
+             "qkv": (2048, 3072, hb.EPI_SCALE_STORE), "logits": (2048, 9264, hb.EPI_SCALE_STORE),
+             "qkvp": (1024, 3072, hb.EPI_SCALE_STORE), "op": (1024, 2048, hb.EPI_RESID_EMIT), "wip": (1024, 8192, hb.EPI_SWIGLU_EMIT), "wop": (4096, 2048, hb.EPI_RESID_EMIT)}[a.shape]
 M = a.M
 mpad = (M + 15) // 16 * 16
 Ws = [torch.randint(-30000, 30000, (N // 16, K // 32, 64, 8), dtype=torch.int16, device=d).view(torch.bfloat16) for _ in range(18)]

@@ -158,7 +158,9 @@ def test_compaction_plan_from_zeros():
     # structure recovered from zeros == the kept indices of the pruning pass
     kq = set(keep[pre + "self_attention.q_proj.weight"].tolist()) | set(keep[pre + "self_attention.k_proj.weight"].tolist()) \
         | set(keep[pre + "self_attention.v_proj.weight"].tolist())
-    assert set(torch.nonzero(P.keep_qkv).flatten().tolist()) == kq
+    got = set(torch.nonzero(P.keep_qkv).flatten().tolist())
+    assert got >= kq and len(got) % 32 == 0 and len(got) - len(kq) < 32                          # padded with zero rows
+    assert all((psd[pre + f"self_attention.{n}_proj.weight"][sorted(got - kq)] == 0).all() for n in "qkv")
     assert torch.nonzero(P.live_q_heads).flatten().tolist() == keep[pre + "self_attention.o_proj.weight"].tolist()
     assert torch.nonzero(P.live_hidden).flatten().tolist() == keep[pre + "mlp.wo.weight"].tolist()
     assert int(P.live_q_heads.sum()) == d.gqa_query_heads // 2 and int(P.live_hidden.sum()) == d.n_hidden // 2
@@ -167,5 +169,12 @@ def test_compaction_plan_from_zeros():
     assert cpt.strips_of_heads(torch.tensor([False, True, False, True]), 256) == list(range(24, 32)) + list(range(40, 48))
     idx = cpt.pad_hidden_keep(torch.tensor([True] * 5 + [False] * 11))
     assert idx.tolist() == [0, 1, 2, 3, 4, -1, -1, -1]
+    big = torch.zeros(4096, dtype=torch.bool); big[:300] = True
+    assert cpt.pad_hidden_keep(big).numel() == 512 and int((cpt.pad_hidden_keep(big) < 0).sum()) == 212
+    k = torch.zeros(2048, dtype=torch.bool); k[100:300] = True
+    pk = cpt.pad_keep(k)                                  # full-size K: 256-row granule
+    assert int(pk.sum()) == 256 and pk[100:300].all() and pk[:56].all() and not pk[56:100].any()
+    k2 = torch.zeros(512, dtype=torch.bool); k2[100:300] = True
+    assert int(cpt.pad_keep(k2).sum()) == 224             # small models: whole k-tiles only
     dense = cpt.plan_decoder_layer(sd, pre, d.gqa_query_heads, d.kv_heads, d.cross_query_heads)
     assert not cpt.is_pruned(dense)
