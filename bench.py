@@ -168,16 +168,24 @@ def main():
         breakdown["unit"] = "us between per-launch HIP events of one eager step (each interval carries ~3 us of event/boundary overhead)"
         wi_ms = sess.time_wi_launches(reps=5) * 1e3          # dispatch-level start/stop events per launch
         wi_bytes = sum(L["wi"].nbytes for L in w.dec_layers) / len(w.dec_layers)   # algorithmic bytes of the dominant kernel
-        kname = ("k_gemv_small<NW=16,KPW=4,RS=%d,MULTI>" % (2 if 2 * args.batch <= 2 else 4)) if 2 * args.batch <= 4 \
-            else "k_gemm<MT=%d,NW=4,KPW=16>" % min(4, (2 * args.batch + 15) // 16)
-        roof = {"bound": "hbm", "kernel": kname + " on wi_fused [2048 x 16384] bf16 (SwiGLU epilogue), 18 launches/step",
+        rows = 2 * args.batch
+        wi_k, wi_n = w.dec_layers[0]["wi"].kt * 32, w.dec_layers[0]["wi"].ns * 16
+        # the dispatcher's choice for this shape (dia_gemm in gemm.hip); rocprofv3's kernel name in
+        # profiles/ is the authority
+        if rows <= 4:
+            kname = "k_gemv_small<NW=16,KPW=%d,RS=%d,MULTI>" % (wi_k // 32 // 16, 2 if rows <= 2 else 4)
+        elif rows <= 16:
+            kname = "k_gemm16<NW=8,KPW=%d,MULTI>" % (wi_k // 32 // 8)
+        else:
+            kname = "k_gemm<MT=%d,NW=4,KPW=%d>" % (min(4, (rows + 15) // 16), wi_k // 32 // 4)
+        roof = {"bound": "hbm", "kernel": kname + " on wi_fused [%d x %d] bf16 (SwiGLU epilogue), 18 launches/step" % (wi_k, wi_n),
                 "achieved": round(wi_bytes / (wi_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(wi_bytes / (wi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "bytes_per_launch": wi_bytes, "us_per_launch": round(wi_ms * 1e3, 2), "traffic": None}
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled
         # as the gfx950 guide prescribes); measured offline, committed under profiles/
         tr = os.path.join(ROOT, "profiles", "traffic_wi.json")
-        if os.path.isfile(tr) and args.batch == 1:
+        if os.path.isfile(tr) and args.batch == 1 and not args.pruned:      # measured for exactly this kernel and shape
             try:
                 roof["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
             except Exception:
