@@ -129,12 +129,15 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g = {};
     g.A = d.planes_h; g.a_plane_stride = hs; g.a_ktiles = hkt; g.M = R;
     g.W = L.w_wo; g.KT = L.kt_wo; g.nstrips = L.ns_wo; g.epi = DIA_EPI_RESID_EMIT;
-    // K = 8192 over only D/16 = 128 strips: at M <= 4 two workgroups per strip (cross-workgroup split-K,
-    // fence-free slab hand-off) stream the matrix from twice as many CUs: 12.4 -> 11.2 us per launch.
-    // More splits or more rows lose again to the seam; shapes without a split kernel fall back to one.
-    int wo_sk = (R <= 4 && L.kt_wo % 2 == 0) ? 2 : 1;
+    // K = 8192 over only D/16 = 128 strips: cross-workgroup split-K (fence-free slab hand-off) streams the
+    // matrix from more CUs.  M <= 4: two workgroups per strip, 12.4 -> 11.2 us per launch.  5..16 rows: four
+    // per strip, which also brings the per-wave K range down to what k_gemm16 keeps in registers (23.2 ->
+    // 18.4 us in the step at batch 8).  Shapes without a split kernel fall back to one workgroup per strip.
+    int wo_sk = (R <= 4 && L.kt_wo % 2 == 0) ? 2 : ((R <= 16 && L.kt_wo % 4 == 0) ? 4 : 1);
     if (const char* ev = getenv("DIA_DBG_WO_SK")) wo_sk = atoi(ev) >= 1 && atoi(ev) <= 4 ? atoi(ev) : wo_sk;
     g.sk = wo_sk; g.sk_scratch = wo_sk > 1 ? d.sk_scratch : nullptr; g.sk_tickets = wo_sk > 1 ? d.sk_tickets : nullptr;
+    if (const char* ev = getenv("DIA_DBG_WO_NW")) g.nw = atoi(ev);
+    if (const char* ev = getenv("DIA_DBG_WO_SPW")) g.spw = atoi(ev);
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D;
     g.gnext = (l + 1 < d.n_layer) ? e->layers[l + 1].g_sa : d.g_final;
     g.cmap = L.cmap_next;

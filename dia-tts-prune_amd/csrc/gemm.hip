@@ -543,10 +543,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
       for (int pl = 0; pl < DIA_NPLANES; ++pl)
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], bc[i], acc[0], 0, 0, 0);
     reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
-    if (!MULTI) { if (!splitk_combine(p, tile, strip, tid, &sk_flag)) return; }
+    const bool last_slice = splitk_combine(p, tile, strip, tid, &sk_flag);      // workgroup-uniform; true without split-K
     if (e_thread) {
       const int n0 = strip * 16 + half * 8;
-      run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
+      if (last_slice) run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
       if (MULTI && next < p.nstrips && resid) load_resid(next);
     }
   };
@@ -564,19 +564,15 @@ template <int NW, int KPW>
 int launch_g16(const GemmK& k, hipStream_t st) {
   const size_t smem = sizeof(f32x4) * NW * 64 + sizeof(float) * (16 * 17 + 16);
   const int sk = k.KT / (NW * KPW);
-  if (sk > 1) {
-    launch_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
-    return dia_check_launch("k_gemm16");
-  }
   int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
   if (const char* e = getenv("DIA_DBG_SPW")) spw = atoi(e);
   if constexpr (!(NW == 16 && KPW >= 4)) {
-    if (spw > 1) {
-      launch_kernel(k_gemm16<NW, KPW, true>, dim3((k.nstrips + spw - 1) / spw), dim3(NW * 64), smem, st, k);
+    if (spw > 1) {      // persistent multi-strip form, with or without split-K: A fragments loaded once per workgroup
+      launch_kernel(k_gemm16<NW, KPW, true>, dim3((k.nstrips + spw - 1) / spw, sk), dim3(NW * 64), smem, st, k);
       return dia_check_launch("k_gemm16");
     }
   }
-  launch_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+  launch_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
   return dia_check_launch("k_gemm16");
 }
 
