@@ -37,6 +37,7 @@ struct SampleK {
   float cfg_scale, temperature, top_p; int top_k;
   int eos, pad, bos, max_delay, ignore_eos, teacher;
   const int* delay; const float* noise; int noise_steps;
+  const int* first_step;
   int* tokens; int* pred; int* cur; int* fsm;
   EmbedK e;
 };
@@ -151,6 +152,8 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
   const int cur = p.cur[b];
   int* fsm = p.fsm + b * 8;
   const bool done = fsm[3] != 0;                    // uniform over the workgroup
+  const int first = p.first_step ? p.first_step[b] : 1;
+  const bool replay = cur < first;                  // audio-prompt rows: nothing sampled, nothing written
 
   // per-wave LDS scratch for the top-p ordering
   float* lp = reinterpret_cast<float*>(smem_raw) + (size_t)c * (2 * VCAP + VCAP);  // [VCAP] probs of survivors
@@ -159,8 +162,8 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
   unsigned short* rk = li + VCAP;                                                   // [VCAP] rank by vocab index
 
   SSTAMP(0);
-  if (!done && c < p.C) {
-    const int n = cur - 1;                                                          // executed steps so far
+  if (!done && !replay && c < p.C) {
+    const int n = cur - first;                                                      // sampled steps so far
     const float* un = p.logits + (long)(2 * b) * p.ld_logits + c * p.V;
     const float* co = p.logits + (long)(2 * b + 1) * p.ld_logits + c * p.V;
     float lg[NV], qn[NV];
@@ -320,11 +323,11 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
       int eos_detected = fsm[0], eos_countdown = fsm[1], bos_countdown = fsm[2];      // same address in every lane
       const int old = ch ? trow[lane] : 0;
       const int d = ch ? p.delay[lane] : 0;
-      int pr = ch ? preds[lane] : 0;
-      if (ch) prow[lane] = pr;
+      int pr = (ch && !replay) ? preds[lane] : -1;
+      if (ch && !replay) prow[lane] = pr;
       const int pr0 = __shfl(pr, 0, 64);
       int finished = 0, last = cur, tk = old;
-      if (!p.teacher) {
+      if (!p.teacher && !replay) {
         if (!eos_detected && pr0 == p.eos && !p.ignore_eos) { eos_detected = 1; eos_countdown = p.max_delay; }
         if (eos_countdown > 0) {
           const int after = p.max_delay - eos_countdown;
@@ -409,7 +412,7 @@ extern "C" int dia_sample(const dia_sample_args* a, void* stream) {
   k.logits = a->logits; k.ld_logits = a->ld_logits; k.B = a->B; k.T = a->T; k.C = a->C; k.V = a->V; k.max_tokens = a->max_tokens;
   k.cfg_scale = a->cfg_scale; k.temperature = a->temperature; k.top_p = a->top_p; k.top_k = a->top_k;
   k.eos = a->eos; k.pad = a->pad; k.bos = a->bos; k.max_delay = a->max_delay; k.ignore_eos = a->ignore_eos; k.teacher = a->teacher;
-  k.delay = a->delay; k.noise = a->noise; k.noise_steps = a->noise_steps;
+  k.delay = a->delay; k.noise = a->noise; k.noise_steps = a->noise_steps; k.first_step = a->first_step;
   k.tokens = a->tokens; k.pred = a->pred; k.cur = a->cur; k.fsm = a->fsm;
   dia_embed_args ea = a->embed;
   ea.tokens = a->tokens; ea.cur = a->cur; ea.B = a->B; ea.T = a->T; ea.C = a->C; ea.V = a->V;

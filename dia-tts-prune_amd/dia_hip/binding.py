@@ -77,7 +77,7 @@ class SampleArgs(C.Structure):
         ("ignore_eos", C.c_int32), ("teacher", C.c_int32),
         ("delay", C.c_void_p), ("noise", C.c_void_p), ("noise_steps", C.c_int32), ("_pad0", C.c_int32),
         ("tokens", C.c_void_p), ("pred", C.c_void_p), ("cur", C.c_void_p), ("fsm", C.c_void_p),
-        ("embed", EmbedArgs),
+        ("first_step", C.c_void_p), ("embed", EmbedArgs),
     ]
 
 

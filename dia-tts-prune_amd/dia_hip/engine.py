@@ -184,7 +184,9 @@ class DecodeSession:
                  top_p: float = 0.95, top_k: int = 35, seeds: Optional[Sequence[Optional[int]]] = None,
                  noise: Optional[torch.Tensor] = None, ignore_eos: bool = False,
                  teacher_tokens: Optional[Sequence[np.ndarray]] = None, stream: Optional[torch.cuda.Stream] = None,
-                 s_cap: Optional[int] = None):
+                 s_cap: Optional[int] = None, audio_prompts: Optional[Sequence[Optional[np.ndarray]]] = None):
+        """audio_prompts: per utterance None or int codes [Tp, C] (reference model.py:311-353).  The prompt
+        rows are replayed through the decode step before sampling starts (semantics: oracle.generate)."""
         cfg, dev = w.cfg, w.device
         self.w, self.cfg, self.dev = w, cfg, dev
         d, da = cfg.model.decoder, cfg.data
@@ -239,17 +241,30 @@ class DecodeSession:
 
         # token buffer + state machine (state.py:178-208; model.py:736-741)
         from .tokens import delayed_prefill
-        prefill, pstep = delayed_prefill(cfg)
         tok = np.full((B, self.T, self.C), -1, dtype=np.int32)
-        tok[:, : prefill.shape[0]] = prefill[None]
+        self.first_steps = []
+        for b in range(B):
+            pr = None if audio_prompts is None else audio_prompts[b]
+            if pr is not None:
+                pr = np.asarray(pr)
+                if pr.ndim == 3 and pr.shape[0] == 1:
+                    pr = pr[0]
+                if pr.ndim != 2 or pr.shape[1] != self.C:
+                    raise ValueError(f"Unexpected audio_prompt shape: {pr.shape}. Expected [T, C] or [1, T, C].")   # model.py:316
+            prefill, pstep = delayed_prefill(cfg, pr)
+            if prefill.shape[0] > self.T:
+                raise ValueError(f"audio prompt of {pstep - 1} frames does not fit audio_length {self.T}")
+            tok[b, : prefill.shape[0]] = prefill
+            self.first_steps.append(int(pstep))
         if self.teacher:
             for b in range(B):
                 tt = np.asarray(teacher_tokens[b], dtype=np.int32)
                 tok[b, : tt.shape[0]] = tt
-        self.prefill_step = pstep
+        self.prefill_step = 1                     # every utterance starts at step 1; steps < first_step replay the prompt
+        self.first_step = torch.tensor(self.first_steps, dtype=torch.int32, device=dev)
         self.tokens = torch.from_numpy(tok).to(dev)
         self.pred = torch.full((B, self.T, self.C), -1, dtype=torch.int32, device=dev)
-        self.cur = torch.full((B,), pstep, dtype=torch.int32, device=dev)
+        self.cur = torch.full((B,), 1, dtype=torch.int32, device=dev)
         fsm = np.zeros((B, 8), dtype=np.int32)
         fsm[:, 1] = -1
         fsm[:, 2] = md
@@ -306,6 +321,7 @@ class DecodeSession:
         s.ignore_eos, s.teacher = int(self.ignore_eos), int(self.teacher)
         s.delay, s.noise, s.noise_steps = hb.ptr(self.delay), hb.ptr(self.noise), self.noise_steps
         s.tokens, s.pred, s.cur, s.fsm = hb.ptr(self.tokens), hb.ptr(self.pred), hb.ptr(self.cur), hb.ptr(self.fsm)
+        s.first_step = hb.ptr(self.first_step) if any(f != 1 for f in self.first_steps) else None
         s.embed = self._embed_args()
         return s
 
@@ -520,7 +536,7 @@ class DecodeSession:
         out = []
         for b in range(self.B):
             last = int(fsm[b, 4]) if fsm[b, 3] else int(cur[b]) - 1
-            out.append(UtteranceResult(tok[b], tok[b, self.prefill_step: last + 1].copy(), last, prd[b], self.lens[b]))
+            out.append(UtteranceResult(tok[b], tok[b, self.first_steps[b]: last + 1].copy(), last, prd[b], self.lens[b]))   # model.py:831
         return out
 
     # ------------------------------------------------------------------ accounting

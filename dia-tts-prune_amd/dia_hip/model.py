@@ -138,20 +138,21 @@ class Dia:
 
     def _run(self, texts: Sequence[str], max_tokens, cfg_scale, temperature, top_p, top_k,
              seeds: Optional[Sequence[Optional[int]]], verbose: bool, ignore_eos: bool = False,
-             use_graph: bool = True) -> List[UtteranceResult]:
+             use_graph: bool = True, audio_prompts: Optional[Sequence[Optional[np.ndarray]]] = None) -> List[UtteranceResult]:
         if self.model is None:
             raise RuntimeError("no weights loaded")
         ids = [encode_text(t, self.config) for t in texts]
         t0 = time.time()
         with torch.cuda.device(self.device):
             s = DecodeSession(self.model, ids, kv_dtype=self._kv_dtype(), max_tokens=max_tokens, cfg_scale=cfg_scale,
-                              temperature=temperature, top_p=top_p, top_k=top_k, seeds=seeds, ignore_eos=ignore_eos)
+                              temperature=temperature, top_p=top_p, top_k=top_k, seeds=seeds, ignore_eos=ignore_eos,
+                              audio_prompts=audio_prompts)
             try:
                 s.prefill()
                 s.sync()
                 t1 = time.time()
                 if verbose:
-                    print(f"generate: prefill {t1 - t0:.3f}s; starting generation loop from step {s.prefill_step}")
+                    print(f"generate: prefill {t1 - t0:.3f}s; prefill audio steps {s.first_steps}; starting generation loop")
                 s.run(use_graph=use_graph)
                 res = s.results()
                 if verbose:
@@ -166,10 +167,14 @@ class Dia:
     def generate_batch(self, texts: Sequence[str], max_tokens: Optional[int] = None, cfg_scale: float = 3.0,
                        temperature: float = 1.3, top_p: float = 0.95, cfg_filter_top_k: int = 35,
                        seeds: Optional[Sequence[Optional[int]]] = None, verbose: bool = False,
-                       ignore_eos: bool = False) -> List[np.ndarray]:
-        """B utterances in one decode loop; returns the codec inputs [1, C, T'_b] per utterance."""
-        eff = [effective_text(t) for t in texts]
-        res = self._run(eff, max_tokens, cfg_scale, temperature, top_p, cfg_filter_top_k, seeds, verbose, ignore_eos)
+                       ignore_eos: bool = False, audio_prompts: Optional[Sequence[Optional[np.ndarray]]] = None,
+                       audio_prompt_texts: Optional[Sequence[Optional[str]]] = None) -> List[np.ndarray]:
+        """B utterances in one decode loop; returns the codec inputs [1, C, T'_b] per utterance.
+        audio_prompts: per utterance None or codes [Tp, C]; audio_prompt_texts: their transcripts."""
+        apt = audio_prompt_texts or [None] * len(texts)
+        eff = [effective_text(t, a) for t, a in zip(texts, apt)]
+        res = self._run(eff, max_tokens, cfg_scale, temperature, top_p, cfg_filter_top_k, seeds, verbose, ignore_eos,
+                        audio_prompts=audio_prompts)
         return [codes_for_codec(r.codes, self.config) for r in res]
 
     @torch.inference_mode()
@@ -190,17 +195,24 @@ class Dia:
         is accepted and ignored (there is nothing to compile)."""
         if audio_prompt is not None and not audio_prompt_text:
             raise ValueError("`audio_prompt_text` is required when `audio_prompt` is provided.")
-        if audio_prompt is not None:
-            # the reference's own audio-prompt prefill crashes (SURVEY.md App. A4); not on this path yet
-            print("Error during preparation: audio-prompt prefill is not implemented on the HIP path")
-            return None
         if seed is not None:
             torch.manual_seed(seed)
             np.random.seed(seed)
         eff = effective_text(text, audio_prompt_text)
+        prompt = None
+        if audio_prompt is not None:
+            # model.py:372-379: a path is encoded by the codec, a tensor is taken as codes [T, C] / [1, T, C].
+            # The prompt rows are replayed through the decode step (semantic decision: DESIGN.md, audio prompt).
+            try:
+                pt = self.load_audio(audio_prompt) if isinstance(audio_prompt, str) else audio_prompt
+                prompt = pt.detach().cpu().numpy() if isinstance(pt, torch.Tensor) else np.asarray(pt)
+            except Exception as e:
+                print(f"Error during preparation: {e}")             # model.py:729-733
+                return None
         try:
             res = self._run([eff], max_tokens, cfg_scale, temperature, top_p, cfg_filter_top_k,
-                            None if seed is None else [seed], verbose)[0]
+                            None if seed is None else [seed], verbose,
+                            audio_prompts=None if prompt is None else [prompt])[0]
         except Exception as e:
             print(f"Error during generation loop: {e}")
             import traceback

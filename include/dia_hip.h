@@ -196,13 +196,18 @@ typedef struct {
   int32_t ignore_eos;       /* perf runs: natural EOS does not start the countdown */
   int32_t teacher;          /* parity runs: record samples in `pred`, leave `tokens` untouched */
   const int32_t* delay;     /* [C] device */
-  const float* noise;       /* [B][noise_steps][C][V] Exp(1) variates; step index = cur-1 */
+  const float* noise;       /* [B][noise_steps][C][V] Exp(1) variates; step index = cur - first_step[b] */
   int32_t noise_steps;
   int32_t _pad0;
   int32_t* tokens;          /* [B][T][C] */
   int32_t* pred;            /* [B][T][C] raw samples per step (row cur) */
   int32_t* cur;             /* [B] in/out */
   int32_t* fsm;             /* [B][4]: eos_detected, eos_countdown, bos_countdown, done */
+  /* audio prompt (model.py:311-353, 406-422): first_step[b] = 1 + prompt frames = the first step that is
+   * sampled.  Steps cur < first_step[b] REPLAY rows already in the token buffer: nothing is sampled or
+   * written, the state machine does not move, only cur advances and the next row is embedded; the noise
+   * row of step cur is cur - first_step[b].  NULL = no prompt anywhere (first_step 1). */
+  const int32_t* first_step;
   dia_embed_args embed;     /* next-step embedding; embed.tokens/cur are taken from above */
 } dia_sample_args;
 int dia_sample(const dia_sample_args* a, void* stream);

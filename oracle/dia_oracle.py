@@ -440,8 +440,20 @@ def generate(w: Dict[str, torch.Tensor], cfg, text: str, *, max_tokens: Optional
              cfg_filter_top_k: int = 35, seed: Optional[int] = None, mirror: bool = False,
              noise: Optional[torch.Tensor] = None, forced_tokens: Optional[np.ndarray] = None,
              keep_logits: bool = True, max_steps: Optional[int] = None,
-             ignore_eos: bool = False) -> GenResult:
-    """reference model.py:631-846 without audio prompt, up to (not including) the codec.
+             ignore_eos: bool = False, audio_prompt: Optional[np.ndarray] = None,
+             audio_prompt_text: Optional[str] = None) -> GenResult:
+    """reference model.py:631-846, up to (not including) the codec.
+
+    ``audio_prompt`` [Tp, C] codes (model.py:311-353, 406-422): SEMANTIC DECISION, parity unpinned for this
+    argument.  The reference cannot run it (KVCache.prefill returns nothing, state.py:105-109 vs
+    layers.py:297 — SURVEY.md App. A4) and what it sketches is inconsistent with its own decode loop (prefill
+    positions r for token row r where decode uses r+1; current_idx = len-1 so the first decoded step would
+    overwrite the last prefilled slot — App. B6).  Here the prompt rows are REPLAYED through the decode step:
+    token row r -> cache slot r at RoPE position r+1 for r = 0..P-2 (P = 1 + Tp), exactly what the loop does
+    for every generated row, with nothing sampled or written and no RNG draw; generation proper then starts
+    at step P with the reference's own bookkeeping (bos_countdown, masked write, slice [P : dec_step+1]).
+    The token-buffer preparation itself (model.py:291-353) runs in the reference and is pinned by
+    tests/golden/ref_prompt.npz.
 
     ``noise`` [steps,C,V]: explicit Exp(1) variates (argmax(p/q) draw); else the torch global
     generator seeded with ``seed`` is used through torch.multinomial exactly like the
@@ -453,14 +465,16 @@ def generate(w: Dict[str, torch.Tensor], cfg, text: str, *, max_tokens: Optional
     if seed is not None:
         torch.manual_seed(seed)
         np.random.seed(seed)
-    text = effective_text(text)
+    text = effective_text(text, audio_prompt_text)
     T = dm.T if max_tokens is None else max_tokens
     md = max(dm.delay)
     t0 = time.time()
     st = prepare(w, dm, text_tokens(text, dm), mirror)
-    prefill, prefill_step = delayed_prefill(dm)
+    prefill, prefill_step = delayed_prefill(dm, audio_prompt)
     tokens = np.full((dm.T, dm.C), -1, dtype=np.int32)                     # state.py:178-188
     tokens[: prefill.shape[0]] = prefill                                  # state.py:205-208
+    for cur in range(1, prefill_step):                                     # prompt replay (see docstring)
+        decode_step(w, st, tokens[cur - 1], cur)
     prep_s = time.time() - t0
 
     dec_step = prefill_step - 1

@@ -119,6 +119,26 @@ def run_reference(M, L, S, cfg_ref, sd, text, seed, max_tokens):
     return cap, dia
 
 
+def prompt_goldens(M, RC, C, O):
+    """audio-prompt token-buffer preparation (model.py:291-353) from the reference's own helper; the decoder
+    prefill after it cannot run in the reference (App. A4), so only this part is pinned."""
+    cfg = C.tiny_config()
+    cfg_ref = RC.DiaConfig.model_validate(C.config_to_json_dict(cfg))
+    dia = M.Dia(cfg_ref, "float32", torch.device("cpu"))
+    rs = np.random.RandomState(11)
+    rec = {}
+    for i, tp in enumerate((1, 5, 23)):
+        codes = rs.randint(0, 1024, size=(tp, cfg.data.channels)).astype(np.int32)
+        arg = torch.from_numpy(codes) if i != 1 else torch.from_numpy(codes)[None]      # [T,C] and [1,T,C] forms
+        pd, ps = dia._prepare_audio_prompt(arg)
+        mine, ms = O.delayed_prefill(O.Dims.of(cfg), codes)
+        assert ms == ps and np.array_equal(mine, pd.numpy())
+        rec[f"codes_{i}"] = codes; rec[f"delayed_{i}"] = pd.numpy().astype(np.int32); rec[f"step_{i}"] = np.int32(ps)
+    rec["n"] = np.int32(3)
+    np.savez_compressed(os.path.join(HERE, "ref_prompt.npz"), **rec)
+    print("ref_prompt.npz written")
+
+
 def main():
     torch.set_num_threads(1)
     from dia_hip import config as C
@@ -127,6 +147,9 @@ def main():
 
     M, L, S = import_reference()
     import dia.config as RC
+    prompt_goldens(M, RC, C, O)
+    if "--only-prompt" in sys.argv:
+        return
 
     out = {}
     for name, cfg, std, text, max_tokens, keep in (

@@ -309,3 +309,53 @@ def test_edge_texts_and_full_length(mid):
         print(f"utterance {b}: free-running token rows identical up to row {first_bad} of {mt}")
         assert first_bad >= 64
         assert out[b].last_step == r.last_step == mt - 2
+
+
+def test_audio_prompt_matches_oracle(mid):
+    """audio-prompt (voice-clone) prefill.  Prompt rows are replayed through the decode
+    step on the device (dia_sample_args.first_step); tokens bit-exact and logits within tolerance against
+    the oracle's statement of the same semantics, single and batched with mixed prompt lengths (one
+    utterance without a prompt), eager and graph replay."""
+    cfg, sd, w = mid
+    dm = O.Dims.of(cfg)
+    rs = np.random.RandomState(5)
+    prompts = [rs.randint(0, 1024, size=(7, dm.C)).astype(np.int32), None, rs.randint(0, 1024, size=(19, dm.C)).astype(np.int32)]
+    ptexts = ["[S1] A prompt transcript.", None, "[S2] Another one, a bit longer."]
+    mt, seeds = 52, [42, 7, 123]
+    runs = []
+    torch.set_num_threads(cpu_threads())
+    for t, p, pt, sd_ in zip(TEXTS, prompts, ptexts, seeds):
+        nz = O.exp_noise(sd_, mt - 1, dm.C, dm.tgt_vocab)
+        runs.append((O.generate(sd, cfg, t, max_tokens=mt, noise=nz, mirror=False, audio_prompt=p, audio_prompt_text=pt), nz))
+    ids = [encode_text(effective_text(t, pt), cfg) for t, pt in zip(TEXTS, ptexts)]
+    for use_graph in (False, True):
+        s = DecodeSession(w, ids, kv_dtype="f32", max_tokens=mt, noise=torch.stack([nz for _, nz in runs]), audio_prompts=prompts)
+        assert s.first_steps == [8, 1, 20]
+        s.prefill()
+        if use_graph:
+            s.run(use_graph=True, poll=8)
+        else:
+            worst = 0.0
+            for step in range(1, mt):
+                s.decode(1, use_graph=False)
+                lg = s.logits_host()
+                for b, (r, _) in enumerate(runs):
+                    k = step - r.prefill_step                      # index of this step among the sampled ones
+                    if 0 <= k < len(r.logits):
+                        worst = max(worst, float(np.abs(lg[b] - r.logits[k]).max()))
+            print(f"audio-prompt logits max-abs err {worst:.3e}")
+            assert worst <= LOGIT_TOL
+        out = s.results(); s.close()
+        for b, (r, _) in enumerate(runs):
+            assert np.array_equal(out[b].tokens, r.tokens), (use_graph, b)
+            assert out[b].last_step == r.last_step and np.array_equal(out[b].codes, r.codes)
+    # API surface: tensor prompt [T, C] and [1, T, C]; transcript required (model.py:671-672)
+    dia = Dia.from_state_dict(cfg, sd, "float32", torch.device("cuda:0"))
+    nz0 = runs[0][1]
+    codes = dia.generate_batch([TEXTS[0]], max_tokens=mt, seeds=[42], audio_prompts=[prompts[0]], audio_prompt_texts=[ptexts[0]])[0]
+    assert np.array_equal(codes, codes_for_codec(runs[0][0].codes, cfg))
+    assert dia.generate(TEXTS[0], max_tokens=mt, seed=42, audio_prompt=torch.from_numpy(prompts[0])[None], audio_prompt_text=ptexts[0]) is None  # no codec offline
+    assert np.array_equal(dia.last_codes, codes)
+    with pytest.raises(ValueError):
+        dia.generate("x", audio_prompt=torch.zeros(3, 9))
+    assert dia.generate("x", audio_prompt="/nonexistent.wav", audio_prompt_text="[S1] y") is None     # codec missing -> printed, None

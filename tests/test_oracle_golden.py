@@ -92,3 +92,40 @@ def test_pruned_model(golden):
     assert np.array_equal(r.tokens, g["tokens"])
     for i, s in enumerate(g["logit_steps"]):
         assert np.abs(r.logits[int(s)] - g["logits"][i]).max() <= 1e-5
+
+
+def test_audio_prompt_token_buffer(golden):
+    """model.py:291-353 with a prompt: the reference's own _prepare_audio_prompt outputs"""
+    from dia_hip.tokens import delayed_prefill
+    g = golden("ref_prompt.npz")
+    cfg = C.tiny_config()
+    for i in range(int(g["n"])):
+        codes = g[f"codes_{i}"]
+        for got, step in (O.delayed_prefill(O.Dims.of(cfg), codes), delayed_prefill(cfg, codes)):
+            assert step == int(g[f"step_{i}"]) and np.array_equal(got, g[f"delayed_{i}"])
+
+
+def test_audio_prompt_replay_semantics():
+    """The prompt rows go through the decode step exactly like generated rows (oracle.generate docstring):
+    a run prompted with rows the model generated itself continues with the same K/V cache contents as the
+    run that generated them — checked through the logits of the first sampled step."""
+    cfg = C.tiny_config()
+    dm = O.Dims.of(cfg)
+    torch.set_num_threads(1)
+    sd = synthetic_state_dict(cfg, seed=1234, std=0.08)
+    text = "[S1] Hello there. [S2] Hi!"
+    tp = 6
+    codes = np.random.RandomState(3).randint(0, 1024, size=(tp, dm.C)).astype(np.int32)
+    mt = tp + 1 + 20
+    nz = O.exp_noise(9, mt - 1, dm.C, dm.tgt_vocab)
+    r = O.generate(sd, cfg, text, max_tokens=mt, noise=nz, audio_prompt=codes, audio_prompt_text="[S1] Before.")
+    assert r.prefill_step == tp + 1 and len(r.logits) == mt - 1 - tp
+    # teacher-forced run over the same buffer without a prompt: step P of it sees the same cache and input row
+    eff = O.effective_text(text, "[S1] Before.")
+    st = O.prepare(sd, dm, O.text_tokens(eff, dm), False)
+    for cur in range(1, tp + 2):
+        lg = O.decode_step(sd, st, r.tokens[cur - 1], cur)
+    assert np.abs(lg.numpy() - r.logits[0]).max() <= 1e-6
+    # rows of the prompt are never overwritten; the slice handed on starts after them (model.py:831)
+    pre, P = O.delayed_prefill(dm, codes)
+    assert np.array_equal(r.tokens[:P], pre[:P]) and r.codes.shape[0] == r.last_step - P + 1
