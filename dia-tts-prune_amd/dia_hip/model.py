@@ -63,7 +63,12 @@ class Dia:
         hb.lib()                                        # fail now, not at first generate()
 
     # ------------------------------------------------------------------ loaders
-    def _install(self, sd: Dict[str, torch.Tensor]) -> None:
+    def _install(self, sd: Dict[str, torch.Tensor], adapter_path: Optional[str] = None) -> None:
+        if any("lora_" in k for k in sd):           # model.py:170-172: adapter keys of a half-merged checkpoint are dropped
+            sd = {k: v for k, v in sd.items() if "lora_" not in k}
+        if adapter_path:
+            from .lora import merge_lora_state_dict
+            sd = merge_lora_state_dict(sd, adapter_path)
         missing, unexpected = W.check_state_dict(self.config, sd)
         if unexpected:
             print(f"Warning: Unexpected keys found in checkpoint: {unexpected}")
@@ -83,9 +88,11 @@ class Dia:
     @classmethod
     def from_local(cls, config_path: str, checkpoint_path: str,
                    compute_dtype: Union[str, ComputeDtype] = ComputeDtype.FLOAT32,
-                   device: Optional[torch.device] = None, load_dac: bool = True) -> "Dia":
+                   device: Optional[torch.device] = None, load_dac: bool = True,
+                   adapter_path: Optional[str] = None) -> "Dia":
         """reference model.py:139-187: config JSON + pickled/safetensors state_dict (this is the
-        loader for ``offline_prune.py`` outputs)."""
+        loader for ``offline_prune.py`` outputs).  ``adapter_path``: LoRA adapter directory merged into the
+        dense weights before they are tiled (reference cli.py:166-174 wraps with PEFT at run time)."""
         config = DiaConfig.load(config_path)
         if config is None:
             raise FileNotFoundError(f"Config file not found at {config_path}")
@@ -96,7 +103,7 @@ class Dia:
             raise FileNotFoundError(f"Checkpoint file not found at {checkpoint_path}")
         except Exception as e:
             raise RuntimeError(f"Error loading checkpoint from {checkpoint_path}") from e
-        dia._install(sd)
+        dia._install(sd, adapter_path)
         if load_dac:
             dia._load_dac_model()
         return dia
@@ -104,7 +111,8 @@ class Dia:
     @classmethod
     def from_pretrained(cls, model_name: str = "nari-labs/Dia-1.6B",
                         compute_dtype: Union[str, ComputeDtype] = ComputeDtype.FLOAT32,
-                        device: Optional[torch.device] = None, load_dac: bool = True, **kwargs) -> "Dia":
+                        device: Optional[torch.device] = None, load_dac: bool = True,
+                        adapter_path: Optional[str] = None, **kwargs) -> "Dia":
         """reference model.py:189-236.  ``model_name`` must be a local directory holding
         ``config.json`` and ``model.safetensors`` / ``pytorch_model.bin`` (hub download needs a network)."""
         p = Path(model_name)
@@ -114,7 +122,7 @@ class Dia:
         cfg_path, ckpt = W.find_checkpoint_in_dir(str(p))
         config = W.read_hub_config(cfg_path)
         dia = cls(config, compute_dtype, device)
-        dia._install(W.load_state_dict_file(ckpt))
+        dia._install(W.load_state_dict_file(ckpt), adapter_path)
         if load_dac:
             dia._load_dac_model()
         return dia

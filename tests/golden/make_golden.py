@@ -139,6 +139,32 @@ def prompt_goldens(M, RC, C, O):
     print("ref_prompt.npz written")
 
 
+def chunk_goldens():
+    """text chunking of the Gradio front-end (app.py:79-127).  app.py cannot be imported (it loads a model and
+    needs gradio at import time), so the four pure helper functions are compiled from its source with ast and
+    executed here; only their inputs and outputs are recorded."""
+    import ast
+    src = open(os.path.join(REF, "app.py")).read()
+    want = {"count_effective_length", "auto_adjust_chunk_size", "split_by_words_respecting_special_tokens", "batch_chunks"}
+    mod = ast.Module(body=[n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in want], type_ignores=[])
+    ns = {}
+    exec(compile(mod, "app_helpers", "exec"), ns)
+    base = "[S1] Dia is an open weights text to dialogue model. [S2] You get full control over scripts and voices. "
+    texts = [base, base * 12, "[S1] short", "word " * 40 + "supercalifragilisticexpialidocious" * 3 + " [S2] end", base * 50, "   ", ""]
+    rec = {"n": np.int32(len(texts))}
+    for i, t in enumerate(texts):
+        rec[f"text_{i}"] = np.array(t)
+        rec[f"len_{i}"] = np.int32(ns["count_effective_length"](t))
+        for user in (0, 40):
+            cs = ns["auto_adjust_chunk_size"](t, user)
+            chunks = ns["split_by_words_respecting_special_tokens"](t, max_effective_chars=cs)
+            rec[f"cs_{i}_{user}"] = np.int32(cs)
+            rec[f"chunks_{i}_{user}"] = np.array(chunks, dtype=object) if False else np.array(["\x00".join(chunks)])
+            rec[f"batches_{i}_{user}"] = np.array([len(b) for b in ns["batch_chunks"](chunks, 4)], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "ref_chunks.npz"), **rec)
+    print("ref_chunks.npz written")
+
+
 def main():
     torch.set_num_threads(1)
     from dia_hip import config as C
@@ -148,6 +174,7 @@ def main():
     M, L, S = import_reference()
     import dia.config as RC
     prompt_goldens(M, RC, C, O)
+    chunk_goldens()
     if "--only-prompt" in sys.argv:
         return
 

@@ -359,3 +359,52 @@ def test_audio_prompt_matches_oracle(mid):
     with pytest.raises(ValueError):
         dia.generate("x", audio_prompt=torch.zeros(3, 9))
     assert dia.generate("x", audio_prompt="/nonexistent.wav", audio_prompt_text="[S1] y") is None     # codec missing -> printed, None
+
+
+def test_callers_cli_adapter_and_chunk_chain(mid, tmp_path):
+    """SURVEY.md §8(f)-2/(f)-4 on the device: a LoRA adapter merged at load equals running the merged
+    dense weights; the CLI writes the same codes as the API; chunk chaining prompts batch i+1 with batch i."""
+    import json, sys
+    from dia_hip import callers as CL
+    from dia_hip.lora import merge_lora_state_dict
+    cfg, sd, w = mid
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mdir = tmp_path / "model"; mdir.mkdir()
+    torch.save(sd, mdir / "pytorch_model.bin"); cfg.save(mdir / "config.json")
+    # adapter on two modules
+    torch.manual_seed(1)
+    qn = "decoder.layers.0.self_attention.q_proj"
+    wq = sd[qn + ".weight"]
+    ad = tmp_path / "adapter"; ad.mkdir()
+    json.dump(dict(r=4, lora_alpha=8), open(ad / "adapter_config.json", "w"))
+    torch.save({f"base_model.model.{qn}.lora_A.weight": 0.5 * torch.randn(4, wq.shape[0]),
+                f"base_model.model.{qn}.lora_B.weight": 0.5 * torch.randn(wq[0].numel(), 4)}, ad / "adapter_model.bin")
+    merged = merge_lora_state_dict(sd, str(ad))
+    dev = torch.device("cuda:0")
+    want = Dia.from_state_dict(cfg, merged, "float32", dev).generate_codes(TEXTS[1], max_tokens=30, seed=3)
+    base = Dia.from_state_dict(cfg, sd, "float32", dev).generate_codes(TEXTS[1], max_tokens=30, seed=3)
+    got = Dia.from_pretrained(str(mdir), "float32", dev, load_dac=False, adapter_path=str(ad)).generate_codes(TEXTS[1], max_tokens=30, seed=3)
+    assert np.array_equal(got, want) and not np.array_equal(got, base)
+    # CLI
+    sys.path.insert(0, root)
+    import cli
+    out = tmp_path / "o" / "codes.npy"
+    rc = cli.main([TEXTS[1], "--codes-output", str(out), "--no-dac", "--model-path", str(mdir), "--adapter-path", str(ad),
+                   "--compute-dtype", "float32", "--max-tokens", "30", "--seed", "3"])
+    assert rc == 0 and np.array_equal(np.load(out), want)
+    assert cli.main([TEXTS[1], "--codes-output", str(out), "--no-dac", "--model-path", str(tmp_path / "nope")]) == 1
+    # chunk chaining on codes: two batches, the second prompted with the first (checked against a manual chain)
+    cfg2 = C.mid_config()
+    cfg2 = cfg2.model_copy(update={"data": cfg2.data.model_copy(update={"audio_length": 768})})
+    dia = Dia.from_state_dict(cfg2, sd, "float32", dev)
+    text = ("[S1] Dia is an open weights text to dialogue model. [S2] You get full control over scripts and voices. " * 3).strip()
+    plan = CL.plan_batches(text, chunk_size=0, max_new_tokens=30)
+    assert len(plan) == 2 and all(b == 256 for _, b in plan)
+    parts = CL.generate_long_codes(dia, text, max_new_tokens=30, seed=11)
+    first = dia.generate_batch([plan[0][0]], max_tokens=257, seeds=[11])[0]
+    assert np.array_equal(parts[0], first) and first.shape[-1] > 0
+    prompt = np.ascontiguousarray(first[0].T)
+    second = dia.generate_batch([plan[1][0]], max_tokens=prompt.shape[0] + 1 + 256, seeds=[12], audio_prompts=[prompt],
+                                audio_prompt_texts=[plan[0][0]])[0]
+    assert len(parts) == 2 and np.array_equal(parts[1], second) and second.shape[-1] > 0
+    assert CL.generate_long.__doc__ and dia.dac_model is None
