@@ -55,6 +55,31 @@ def structured_prune_state_dict(cfg: DiaConfig, sd: Dict[str, torch.Tensor], amo
     return out, kept
 
 
+def unstructured_prune_state_dict(cfg: DiaConfig, sd: Dict[str, torch.Tensor], amount: float) -> "OrderedDict[str, torch.Tensor]":
+    """``offline_prune.py --prune-mode unstructured`` (offline_prune.py:101-103 -> pruning_utils.py:42-62):
+    GLOBAL L1 magnitude pruning over all DenseGeneral kernels — the ``round(amount * N)`` entries of smallest
+    absolute value across the concatenation of every prunable kernel (``prune.global_unstructured`` with
+    ``L1Unstructured``: top-k of -|w| over the flattened concatenation, in module order) are zeroed.  The result
+    has no exploitable structure: it loads as dense tensors whose zeros stream like any other value."""
+    if not (0.0 < amount < 1.0):
+        raise ValueError("--prune-amount must be between 0.0 and 1.0 (exclusive).")   # offline_prune.py:58-60
+    names = prunable_names(cfg)
+    flat = torch.cat([sd[k].detach().float().reshape(-1) for k in names])
+    n_prune = int(round(amount * flat.numel()))
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict((k, v.clone()) for k, v in sd.items())
+    if n_prune == 0:
+        return out
+    idx = torch.topk(flat.abs(), k=n_prune, largest=False).indices
+    mask = torch.ones_like(flat, dtype=torch.bool)
+    mask[idx] = False
+    off = 0
+    for k in names:
+        n = sd[k].numel()
+        out[k] = (sd[k].float() * mask[off: off + n].reshape(sd[k].shape)).to(sd[k].dtype)
+        off += n
+    return out
+
+
 def kept_slices(w: torch.Tensor, dim: int = 0) -> np.ndarray:
     """Indices along `dim` whose slice is not identically zero."""
     moved = w.movedim(dim, 0).reshape(w.shape[dim], -1)

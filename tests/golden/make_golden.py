@@ -139,6 +139,29 @@ def prompt_goldens(M, RC, C, O):
     print("ref_prompt.npz written")
 
 
+def unstructured_goldens(M, RC, C):
+    """global unstructured L1 pruning (pruning_utils.py:42-62) of the tiny model through the reference's own
+    utility.  Weights here are plain fp32 normals (not bf16-rounded): magnitude ties would make torch's top-k
+    choice among equals part of the vector."""
+    import dia.pruning_utils as RP
+    from dia_hip.weights import param_shapes
+    cfg = C.tiny_config()
+    cfg_ref = RC.DiaConfig.model_validate(C.config_to_json_dict(cfg))
+    g = torch.Generator().manual_seed(77)
+    sd = {k: (torch.randn(shp, generator=g) * 0.05 if not k.endswith("norm.weight") else torch.ones(shp)) for k, shp in param_shapes(cfg).items()}
+    dia = M.Dia(cfg_ref, "float32", torch.device("cpu"))
+    dia.model.load_state_dict(sd, strict=True)
+    RP.apply_unstructured_pruning(dia.model, amount=0.3)
+    RP.make_pruning_permanent(dia.model)
+    psd = dia.model.state_dict()
+    rec = {"amount": np.float64(0.3), "seed": np.int32(77), "sparsity": np.float64(RP.check_pruning_sparsity(dia.model))}
+    for k in ("encoder.layers.0.mlp.wo.weight", "decoder.layers.1.self_attention.q_proj.weight", "decoder.logits_dense.weight"):
+        rec["zero__" + k] = np.packbits((psd[k] == 0).numpy().reshape(-1))
+    rec["nzero_total"] = np.int64(sum(int((v == 0).sum()) for k, v in psd.items() if v.dim() >= 2 and "embed" not in k))
+    np.savez_compressed(os.path.join(HERE, "ref_unstructured.npz"), **rec)
+    print("ref_unstructured.npz written, sparsity", float(rec["sparsity"]))
+
+
 def chunk_goldens():
     """text chunking of the Gradio front-end (app.py:79-127).  app.py cannot be imported (it loads a model and
     needs gradio at import time), so the four pure helper functions are compiled from its source with ast and
@@ -175,6 +198,7 @@ def main():
     import dia.config as RC
     prompt_goldens(M, RC, C, O)
     chunk_goldens()
+    unstructured_goldens(M, RC, C)
     if "--only-prompt" in sys.argv:
         return
 

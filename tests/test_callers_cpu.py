@@ -99,3 +99,34 @@ def test_cli_argument_surface(capsys):
         cli.main(["x"])                                                          # no output of any kind
     with pytest.raises(SystemExit):
         cli.main(["x", "--output", "o.wav", "--pruned-checkpoint", "m.bin"])     # config required (cli.py:105-106)
+
+
+def test_unstructured_pruning_matches_reference(golden, tmp_path):
+    """pruning_utils.py:42-62 through the reference itself (tests/golden/make_golden.py): identical zero
+    pattern, and the offline_prune.py tool end to end on a local model directory."""
+    from dia_hip.pruning import sparsity, unstructured_prune_state_dict
+    from dia_hip.weights import param_shapes
+    g = golden("ref_unstructured.npz")
+    cfg = C.tiny_config()
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    sd = {k: (torch.randn(shp, generator=gen) * 0.05 if not k.endswith("norm.weight") else torch.ones(shp)) for k, shp in param_shapes(cfg).items()}
+    psd = unstructured_prune_state_dict(cfg, sd, float(g["amount"]))
+    for k in [k[len("zero__"):] for k in g.files if k.startswith("zero__")]:
+        assert np.array_equal(np.packbits((psd[k] == 0).numpy().reshape(-1)), g["zero__" + k]), k
+    assert abs(sparsity(cfg, psd) - float(g["sparsity"])) < 1e-9
+    assert all(torch.equal(psd[k], sd[k]) for k in sd if k.endswith("norm.weight") or "embedding" in k)
+    # the tool: directory in, directory out (offline_prune.py:82-156)
+    sys.path.insert(0, ROOT)
+    import offline_prune
+    src = tmp_path / "m"; src.mkdir()
+    torch.save(sd, src / "pytorch_model.bin"); cfg.save(str(src / "config.json"))
+    assert offline_prune.main(["--model-path", str(src), "--output-dir", str(tmp_path / "u"), "--prune-mode", "unstructured", "--prune-amount", "0.3"]) == 0
+    got = torch.load(tmp_path / "u" / "pytorch_model.bin", weights_only=True)
+    assert all(torch.equal(got[k], psd[k]) for k in psd) and (tmp_path / "u" / "config.json").exists()
+    assert offline_prune.main(["--model-path", str(src), "--output-dir", str(tmp_path / "s"), "--prune-mode", "structured", "--prune-amount", "0.5"]) == 0
+    from dia_hip.pruning import structured_prune_state_dict
+    want, _ = structured_prune_state_dict(cfg, sd, 0.5, dim=0, n=2)
+    got = torch.load(tmp_path / "s" / "pytorch_model.bin", weights_only=True)
+    assert all(torch.equal(got[k], want[k]) for k in want)
+    assert offline_prune.main(["--model-path", str(src), "--output-dir", str(tmp_path / "x"), "--prune-mode", "structured", "--prune-amount", "1.5"]) == 1
+    assert offline_prune.main(["--model-path", str(tmp_path / "none"), "--output-dir", str(tmp_path / "x"), "--prune-mode", "structured", "--prune-amount", "0.5"]) == 1
