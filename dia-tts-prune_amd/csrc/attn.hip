@@ -40,6 +40,7 @@ struct AttnK {
   float* scratch; int* tickets; int max_chunks;
   const int* head_map;
   int v_blocked;
+  int gpw;          // MFMA kernel: granules a wave takes before the keys are split over another workgroup
 };
 
 #ifdef DIA_DBG_STAMPS
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
   const int head_row = by;
   const int NZ = gridDim.z;
   const int ngran = (nkeys + 31) >> 5;
-  const int nchunks = min(NZ, max(1, (ngran + NWV - 1) / NWV));      // workgroups with at least one granule
+  const int nchunks = min(NZ, max(1, (ngran + NWV * p.gpw - 1) / (NWV * p.gpw)));   // workgroups that take keys
   if (chunk >= nchunks) return;
   ASTAMP(1);
   if (p.head_map) {
@@ -651,6 +652,8 @@ extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
   k.cos_t = a->cos_t; k.sin_t = a->sin_t;
   k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles;
   k.head_map = a->head_map; k.v_blocked = a->v_blocked;
+  k.gpw = 1;
+  if (const char* e = getenv(a->mode == DIA_ATTN_CROSS ? "DIA_DBG_GPW_CROSS" : "DIA_DBG_GPW")) { if (atoi(e) > 0) k.gpw = atoi(e); }
   // the kernels decode the mode branch-free and load cur[]/len[] unconditionally (index 0 when the mode
   // does not use them): never hand them a null pointer
   if (!k.cur) k.cur = reinterpret_cast<const int*>(a->cos_t);
