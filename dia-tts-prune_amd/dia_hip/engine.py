@@ -375,51 +375,68 @@ class DecodeSession:
     # ------------------------------------------------------------------ prefill
     def prefill(self, keep_encoder_out: bool = False):
         """Encoder + cross-K/V precompute for every utterance, then the first input embedding.
-        Replaces model.py:382-397 (Encoder.forward layers.py:445-462; precompute_cross_attn_cache 632-669)."""
+        Replaces model.py:382-397 (Encoder.forward layers.py:445-462; precompute_cross_attn_cache 632-669).
+
+        All utterances run as ONE packed batch: utterance b occupies rows [off_b, off_b + L_b) of every
+        activation buffer, off_b a multiple of 16 (whole m-tiles), padding rows zero.  The dense layers
+        (qkv, o, wi, wo) are single GEMMs over all rows — weights are read once per batch and the row count
+        is what the MFMA-tiled kernel wants — while the per-utterance pieces (embedding, K/V prep, the
+        bidirectional attention, the cross-K/V projection with its RoPE positions) address their rows through
+        offset pointers.  Only the non-pad tokens of the cond row are computed (exact)."""
         L = hb.lib()
         cfg, w, dev = self.cfg, self.w, self.dev
         e, d = cfg.model.encoder, cfg.model.decoder
         st = C.c_void_p(self.stream.cuda_stream)
         E, Fe = e.n_embd, e.n_hidden
         eps = float(cfg.model.normalization_layer_epsilon)
-        self.enc_out = []
+        offs, tot = [], 0
+        for Lb in self.lens:
+            offs.append(tot)
+            tot += _ceil(Lb, 16)
+        self.enc_out = [None] * self.B
         with torch.cuda.stream(self.stream):
-            for b in range(self.B):
-                Lb = self.lens[b]
-                if Lb == 0:
-                    self.enc_out.append(None)
-                    continue
-                Lp = _ceil(Lb, 16)
-                mt = Lp // 16
-                ids = torch.from_numpy(self.text_ids[b]).to(dev)
-                x = torch.zeros(Lp, E, dtype=torch.float32, device=dev)
+            if tot > 0:
+                Mp, mt = tot, tot // 16
+                Lmax = _ceil(max(self.lens), 16)
                 ekt, akt, hkt = E // 32, e.n_head * HEAD_DIM // 32, Fe // 32
-                px = torch.zeros(3, mt, ekt, 64, 8, dtype=torch.bfloat16, device=dev)
-                pa = torch.zeros(3, mt, akt, 64, 8, dtype=torch.bfloat16, device=dev)
-                ph = torch.zeros(3, mt, hkt, 64, 8, dtype=torch.bfloat16, device=dev)
-                ssq = torch.zeros(E // 16, Lp, dtype=torch.float32, device=dev)
+                z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)
+                x = z(Mp, E)
+                px, pa, ph = (z(3, mt, kt_, 64, 8, dt=torch.bfloat16) for kt_ in (ekt, akt, hkt))
+                ssq = z(E // 16, Mp)
                 nq = 3 * e.n_head * HEAD_DIM
-                qkv = torch.zeros(Lp, nq, dtype=torch.float32, device=dev)
-                kc = torch.zeros(e.n_head, Lp, HEAD_DIM, dtype=torch.float32, device=dev)
-                vc = torch.zeros(e.n_head, Lp, HEAD_DIM, dtype=torch.float32, device=dev)
-                esc = torch.zeros(max(1, L.dia_attn_scratch_floats(Lb, e.n_head, Lp)), dtype=torch.float32, device=dev)
-                etk = torch.zeros(Lb * e.n_head, dtype=torch.int32, device=dev)
-                hb.check(L.dia_embed_text(hb.ptr(ids), Lb, hb.ptr(w.enc_emb), E, hb.ptr(w.enc_layers[0]["g_sa"]), hb.ptr(x),
-                                          hb.ptr(px), px[0].numel(), ekt, hb.ptr(ssq), Lp, st), "dia_embed_text")
+                qkv = z(Mp, nq)
+                kc, vc = z(e.n_head, Lmax, HEAD_DIM), z(e.n_head, Lmax, HEAD_DIM)
+                esc = z(max(1, L.dia_attn_scratch_floats(Lmax, e.n_head, Lmax)))
+                etk = z(Lmax * e.n_head, dt=torch.int32)
+                live = [b for b in range(self.B) if self.lens[b] > 0]
 
-                def gemm(A, a_kt, W: TiledW, epi, *, ssq_in=None, out=None, ldo=0, gnext=None, P=None, p_kt=0,
-                         ssq_out=None, kv=None, strip_map=None):
+                def rows(t, b, width):              # device pointer of row off_b of a [Mp, width] fp32 buffer
+                    return t.data_ptr() + offs[b] * width * 4
+
+                def planes_at(P, b, kt_):           # device pointer of m-tile off_b/16 of a plane set (bf16)
+                    return P.data_ptr() + (offs[b] // 16) * kt_ * 512 * 2
+
+                for b in live:
+                    ids = torch.from_numpy(self.text_ids[b]).to(dev)
+                    hb.check(L.dia_embed_text(hb.ptr(ids), self.lens[b], hb.ptr(w.enc_emb), E, hb.ptr(w.enc_layers[0]["g_sa"]),
+                                              rows(x, b, E), planes_at(px, b, ekt), px[0].numel(), ekt,
+                                              ssq.data_ptr() + offs[b] * 4, Mp, st), "dia_embed_text")
+
+                def gemm(A, a_kt, W: TiledW, epi, *, M=Mp, a_ptr=None, ssq_ptr=None, ssq_in=False, out=None, ldo=0, gnext=None,
+                         P=None, p_kt=0, ssq_out=False, kv=None, strip_map=None):
                     g = hb.GemmArgs()
-                    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), a_kt, Lb
+                    g.A, g.a_plane_stride, g.a_ktiles, g.M = (a_ptr if a_ptr is not None else hb.ptr(A)), A[0].numel(), a_kt, M
                     g.W, g.KT, g.nstrips, g.epi = hb.ptr(W.t), W.kt, W.ns, epi
-                    if ssq_in is not None:
-                        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq_in), E // 16, 1.0 / E, eps
-                    g.ssq_ld = Lp
+                    sp = ssq_ptr if ssq_ptr is not None else hb.ptr(ssq)
+                    if ssq_in:
+                        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = sp, E // 16, 1.0 / E, eps
+                    g.ssq_ld = Mp
                     g.out, g.ldo = hb.ptr(out), ldo
                     g.gnext = hb.ptr(gnext)
                     if P is not None:
                         g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), p_kt
-                    g.ssq_out = hb.ptr(ssq_out)
+                    if ssq_out:
+                        g.ssq_out = sp
                     g.strip_map = hb.ptr(strip_map)
                     g.kv_vblocked = self.v_blocked if kv is not None else 0
                     if kv is not None:
@@ -428,31 +445,36 @@ class DecodeSession:
                     hb.check(L.dia_gemm(C.byref(g), st), "dia_gemm")
 
                 for i, EL in enumerate(w.enc_layers):
-                    gemm(px, ekt, EL["qkv"], hb.EPI_SCALE_STORE, ssq_in=ssq, out=qkv, ldo=nq)
-                    hb.check(L.dia_enc_kv_prep(hb.ptr(qkv), nq, e.n_head * HEAD_DIM, 2 * e.n_head * HEAD_DIM, e.n_head, Lb, Lp,
-                                               hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(kc), hb.ptr(vc), st), "dia_enc_kv_prep")
-                    a = hb.AttnArgs()
-                    a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_ENC, hb.KV_F32, e.n_head, 1, Lb, Lp
-                    a.q, a.ldq, a.q_off = hb.ptr(qkv), nq, 0
-                    a.kc, a.vc, a.enc_len = hb.ptr(kc), hb.ptr(vc), Lb
-                    a.cos_t, a.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
-                    a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(pa), pa[0].numel(), akt
-                    a.scratch, a.tickets = hb.ptr(esc), hb.ptr(etk)
-                    hb.check(L.dia_attn(C.byref(a), st), "dia_attn(enc)")
-                    gemm(pa, akt, EL["o"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=EL["g_mlp"], P=px, p_kt=ekt, ssq_out=ssq)
-                    gemm(px, ekt, EL["wi"], hb.EPI_SWIGLU_EMIT, ssq_in=ssq, P=ph, p_kt=hkt)
+                    gemm(px, ekt, EL["qkv"], hb.EPI_SCALE_STORE, ssq_in=True, out=qkv, ldo=nq)
+                    for b in live:
+                        Lb = self.lens[b]
+                        qp = rows(qkv, b, nq)
+                        hb.check(L.dia_enc_kv_prep(qp, nq, e.n_head * HEAD_DIM, 2 * e.n_head * HEAD_DIM, e.n_head, Lb, Lmax,
+                                                   hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(kc), hb.ptr(vc), st), "dia_enc_kv_prep")
+                        a = hb.AttnArgs()
+                        a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_ENC, hb.KV_F32, e.n_head, 1, Lb, Lmax
+                        a.q, a.ldq, a.q_off = qp, nq, 0
+                        a.kc, a.vc, a.enc_len = hb.ptr(kc), hb.ptr(vc), Lb
+                        a.cos_t, a.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
+                        a.P, a.p_plane_stride, a.p_ktiles = planes_at(pa, b, akt), pa[0].numel(), akt
+                        a.scratch, a.tickets = hb.ptr(esc), hb.ptr(etk)
+                        hb.check(L.dia_attn(C.byref(a), st), "dia_attn(enc)")
+                    gemm(pa, akt, EL["o"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=EL["g_mlp"], P=px, p_kt=ekt, ssq_out=True)
+                    gemm(px, ekt, EL["wi"], hb.EPI_SWIGLU_EMIT, ssq_in=True, P=ph, p_kt=hkt)
                     gnext = w.enc_layers[i + 1]["g_sa"] if i + 1 < len(w.enc_layers) else w.enc_norm
-                    gemm(ph, hkt, EL["wo"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=gnext, P=px, p_kt=ekt, ssq_out=ssq)
+                    gemm(ph, hkt, EL["wo"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=gnext, P=px, p_kt=ekt, ssq_out=True)
                 # px now holds planes(x * encoder.norm.weight); ssq the row sums of squares of x
                 for i, DL in enumerate(w.dec_layers):
-                    gemm(px, ekt, DL["ckv"], hb.EPI_CROSSKV, ssq_in=ssq,
-                         kv=(hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i]), self.kv_code, d.cross_query_heads, self.S, b),
-                         strip_map=DL["smap_ckv"])
+                    for b in live:
+                        gemm(px, ekt, DL["ckv"], hb.EPI_CROSSKV, M=self.lens[b], a_ptr=planes_at(px, b, ekt),
+                             ssq_ptr=ssq.data_ptr() + offs[b] * 4, ssq_in=True,
+                             kv=(hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i]), self.kv_code, d.cross_query_heads, self.S, b),
+                             strip_map=DL["smap_ckv"])
                 if keep_encoder_out:
-                    inv = torch.rsqrt(ssq[:, :Lb].sum(dim=0) / E + eps)
-                    self.enc_out.append((x[:Lb] * inv[:, None] * w.enc_norm[None, :]).clone())
-                else:
-                    self.enc_out.append(None)
+                    for b in live:
+                        Lb, o = self.lens[b], offs[b]
+                        inv = torch.rsqrt(ssq[:, o: o + Lb].sum(dim=0) / E + eps)
+                        self.enc_out[b] = (x[o: o + Lb] * inv[:, None] * w.enc_norm[None, :]).clone()
             ea = self._embed_args()
             hb.check(L.dia_embed_tokens(C.byref(ea), st), "dia_embed_tokens")
         self.prefilled = True
