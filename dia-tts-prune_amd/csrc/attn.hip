@@ -584,6 +584,198 @@ __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
   attn_finish<G>(p, part, pm_s, pl_s, &last_s, tid, qrow, kvh, head_row, chunk, nchunks);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Encoder self-attention for the packed prefill batch (layers.py:385-462: bidirectional over the L non-pad
+// positions of each utterance, RoPE positions = byte indices).  Two launches per layer for ALL utterances:
+//   k_enc_kv_planes   K = RoPE(k) and V of every packed row as three bf16 planes each (hi+mid+lo == fp32
+//                     exactly): K in row layout [plane][head][row][128], V blocked [plane][head][row/32][128][32]
+//   k_attn_enc_mfma   grid (head, 16-row query tile): S = Q.K^T and O = P.V on MFMA, every operand as three
+//                     planes -> 9 MFMAs per 16x16x32 product, fp32-exact products; 4 waves split the keys in
+//                     32-key granules, online softmax per query row (rows of a wave's 16x16 tiles live in the
+//                     four 16-lane groups), waves merged through LDS.
+// Rows are addressed through row_b[] (utterance of a packed row, -1 = padding), seg_off[] / seg_len[].
+struct EncAttnK {
+  const float* qkv; int ldq, q_off, k_off, v_off, heads, rows;
+  const int* row_b; const int* seg_off; const int* seg_len;
+  const float* cos_t; const float* sin_t;
+  bf16_raw* kp; bf16_raw* vp;          // [3][heads][rows][128], [3][heads][rows/32][128][32]
+  bf16_raw* P; long p_plane_stride; int p_ktiles;
+};
+
+__global__ __launch_bounds__(256) void k_enc_kv_planes(EncAttnK p) {
+  // grid (heads, rows/32): one 32-row key block of one head
+  const int h = blockIdx.x, blk = blockIdx.y, tid = threadIdx.x;
+  const long plane = (long)p.heads * p.rows * HD;
+  bf16_raw* kp = p.kp + ((long)h * p.rows + blk * 32) * HD;
+  bf16_raw* vp = p.vp + ((long)h * (p.rows >> 5) + blk) * HD * 32;
+  for (int t = tid; t < 32 * 64; t += 256) {              // K: RoPE pairs (d, d+64)
+    const int r = t >> 6, d = t & 63, m = blk * 32 + r;
+    const int b = p.row_b[m];
+    float k1 = 0.f, k2 = 0.f;
+    if (b >= 0) {
+      const int pos = m - p.seg_off[b];
+      const float* kr = p.qkv + (long)m * p.ldq + p.k_off + h * HD;
+      const float x1 = kr[d], x2 = kr[d + 64];
+      const float c = p.cos_t[(long)pos * 64 + d], s = p.sin_t[(long)pos * 64 + d];
+      k1 = x1 * c - x2 * s; k2 = x1 * s + x2 * c;
+    }
+    __bf16 a, bb, c3;
+    split3(k1, a, bb, c3);
+    kp[(long)r * HD + d] = *reinterpret_cast<bf16_raw*>(&a); kp[plane + (long)r * HD + d] = *reinterpret_cast<bf16_raw*>(&bb);
+    kp[2 * plane + (long)r * HD + d] = *reinterpret_cast<bf16_raw*>(&c3);
+    split3(k2, a, bb, c3);
+    kp[(long)r * HD + d + 64] = *reinterpret_cast<bf16_raw*>(&a); kp[plane + (long)r * HD + d + 64] = *reinterpret_cast<bf16_raw*>(&bb);
+    kp[2 * plane + (long)r * HD + d + 64] = *reinterpret_cast<bf16_raw*>(&c3);
+  }
+  for (int t = tid; t < 32 * HD; t += 256) {              // V: [dim][key] inside the block
+    const int r = t & 31, d = t >> 5, m = blk * 32 + r;
+    const int b = p.row_b[m];
+    const float v = b >= 0 ? p.qkv[(long)m * p.ldq + p.v_off + h * HD + d] : 0.f;
+    __bf16 a, bb, c3;
+    split3(v, a, bb, c3);
+    vp[d * 32 + r] = *reinterpret_cast<bf16_raw*>(&a); vp[plane + d * 32 + r] = *reinterpret_cast<bf16_raw*>(&bb);
+    vp[2 * plane + d * 32 + r] = *reinterpret_cast<bf16_raw*>(&c3);
+  }
+}
+
+__global__ __launch_bounds__(NT) void k_attn_enc_mfma(EncAttnK p) {
+  __shared__ __attribute__((aligned(16))) bf16_raw qf[4][DIA_NPLANES][16][4][8];     // q planes, A-fragment order
+  __shared__ __attribute__((aligned(16))) bf16_raw pbuf[NWV][DIA_NPLANES][16][32];   // p planes per wave
+  __shared__ float part[NWV * 16 * HD];
+  __shared__ float pm_s[NWV * 16], pl_s[NWV * 16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = blockIdx.x, qt = blockIdx.y;
+  const int arow = lane & 15, akq = lane >> 4;
+  const int b = p.row_b[qt * 16];
+  if (b < 0) return;                                   // a tile of padding rows (tiles never straddle utterances)
+  const int off = p.seg_off[b], len = p.seg_len[b];
+  const long plane = (long)p.heads * p.rows * HD;
+
+  // ---- RoPE(q) of the 16 rows -> three planes in LDS: thread (row = tid>>4, 8 dim pairs)
+  {
+    const int r = tid >> 4, m = qt * 16 + r, pos = min(m - off, len - 1);       // rows past the end: recomputed, never emitted
+    const float* qh = p.qkv + (long)min(m, off + len - 1) * p.ldq + p.q_off + h * HD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = (tid & 15) * 4 + i;
+      const float x1 = qh[d], x2 = qh[d + 64];
+      const float c = p.cos_t[(long)pos * 64 + d], s = p.sin_t[(long)pos * 64 + d];
+      const float qv[2] = {x1 * c - x2 * s, x1 * s + x2 * c};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int D = d + 64 * e;
+        __bf16 a, bb, c3;
+        split3(qv[e], a, bb, c3);
+        qf[D >> 5][0][r][(D >> 3) & 3][D & 7] = *reinterpret_cast<const bf16_raw*>(&a);
+        qf[D >> 5][1][r][(D >> 3) & 3][D & 7] = *reinterpret_cast<const bf16_raw*>(&bb);
+        qf[D >> 5][2][r][(D >> 3) & 3][D & 7] = *reinterpret_cast<const bf16_raw*>(&c3);
+      }
+    }
+  }
+  __syncthreads();
+
+  const float scale = 0.08838834764831845f;
+  f32x4 O[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) O[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mrun[4], lrun[4];                               // rows 4*akq + r of this lane group
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
+  const bf16_raw* Kh = p.kp + ((long)h * p.rows + off) * HD;
+  const bf16_raw* Vh = p.vp + ((long)h * (p.rows >> 5) + (off >> 5)) * HD * 32;
+  const int ngran = (len + 31) >> 5;
+  for (int g = w; g < ngran; g += NWV) {
+    const int key0 = g << 5;
+    f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 qa[DIA_NPLANES];
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl) qa[pl] = *reinterpret_cast<const bf16x8*>(&qf[ks][pl][arow][akq][0]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16_raw* kr = Kh + (long)(key0 + 16 * t + arow) * HD + 32 * ks + 8 * akq;   // rows < seg padded to 32: in bounds
+#pragma unroll
+        for (int kpl = 0; kpl < DIA_NPLANES; ++kpl) {
+          const bf16x8 kb = *reinterpret_cast<const bf16x8*>(kr + kpl * plane);
+#pragma unroll
+          for (int pl = 0; pl < DIA_NPLANES; ++pl) S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[pl], kb, S[t], 0, 0, 0);
+        }
+      }
+    }
+    // online softmax per query row: S[t][r] = score(row 4*akq + r, key key0 + 16t + arow)
+    float alpha[4];
+    const bool v0 = key0 + arow < len, v1 = key0 + 16 + arow < len;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s0 = v0 ? S[0][r] * scale : -INFINITY, s1 = v1 ? S[1][r] * scale : -INFINITY;
+      const float mnew = fmaxf(mrun[r], row16_max(fmaxf(s0, s1)));
+      alpha[r] = (mrun[r] == -INFINITY) ? 0.f : expf(mrun[r] - mnew);
+      const float p0 = (s0 == -INFINITY) ? 0.f : expf(s0 - mnew), p1 = (s1 == -INFINITY) ? 0.f : expf(s1 - mnew);
+      lrun[r] = lrun[r] * alpha[r] + row16_sum(p0 + p1);
+      mrun[r] = mnew;
+      __bf16 a, bb, c3;
+      split3(p0, a, bb, c3);
+      pbuf[w][0][4 * akq + r][arow] = *reinterpret_cast<const bf16_raw*>(&a);
+      pbuf[w][1][4 * akq + r][arow] = *reinterpret_cast<const bf16_raw*>(&bb);
+      pbuf[w][2][4 * akq + r][arow] = *reinterpret_cast<const bf16_raw*>(&c3);
+      split3(p1, a, bb, c3);
+      pbuf[w][0][4 * akq + r][16 + arow] = *reinterpret_cast<const bf16_raw*>(&a);
+      pbuf[w][1][4 * akq + r][16 + arow] = *reinterpret_cast<const bf16_raw*>(&bb);
+      pbuf[w][2][4 * akq + r][16 + arow] = *reinterpret_cast<const bf16_raw*>(&c3);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) O[nb][r] *= alpha[r];
+    bf16x8 pa[DIA_NPLANES];
+#pragma unroll
+    for (int pl = 0; pl < DIA_NPLANES; ++pl) pa[pl] = *reinterpret_cast<const bf16x8*>(&pbuf[w][pl][arow][8 * akq]);
+    const bf16_raw* Vblk = Vh + (long)g * HD * 32;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const bf16_raw* vr = Vblk + (long)(16 * nb + arow) * 32 + 8 * akq;
+#pragma unroll
+      for (int vpl = 0; vpl < DIA_NPLANES; ++vpl) {
+        const bf16x8 vb = *reinterpret_cast<const bf16x8*>(vr + vpl * plane);
+#pragma unroll
+        for (int pl = 0; pl < DIA_NPLANES; ++pl) O[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[pl], vb, O[nb], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();     // pbuf is rewritten by the next granule
+  }
+  // ---- merge the waves: lane holds dims 16*nb + arow of rows 4*akq + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) part[(w * 16 + 4 * akq + r) * HD + 16 * nb + arow] = O[nb][r];
+    if (arow == 0) { pm_s[w * 16 + 4 * akq + r] = mrun[r]; pl_s[w * 16 + 4 * akq + r] = lrun[r]; }
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 4, d0 = (tid & 15) * 8, m = qt * 16 + r;
+    if (m - off >= len) return;                         // padding row inside the last tile of an utterance
+    float mm = -INFINITY;
+#pragma unroll
+    for (int ww = 0; ww < NWV; ++ww) mm = fmaxf(mm, pm_s[ww * 16 + r]);
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Ls = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NWV; ++ww) {
+      const float pmw = pm_s[ww * 16 + r];
+      const float f = (pmw == -INFINITY) ? 0.f : expf(pmw - mm);
+      Ls += pl_s[ww * 16 + r] * f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += part[(ww * 16 + r) * HD + d0 + j] * f;
+    }
+    const float inv = Ls > 0.f ? 1.0f / Ls : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] *= inv;
+    emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, m, h * HD + d0, o);
+  }
+}
+
 __global__ void k_enc_kv_prep(const float* qkv, int ldq, int k_off, int v_off, int heads, int L, int cap,
                               const float* cos_t, const float* sin_t, float* kc, float* vc) {
   // grid (heads, L), 64 threads: thread d handles the RoPE pair (d, d+64)
@@ -694,4 +886,21 @@ extern "C" int dia_enc_kv_prep(const float* qkv, int ldq, int k_off, int v_off, 
   if (!qkv || !kc || !vc || !cos_t || !sin_t || heads <= 0 || L <= 0 || L > cap) return dia_fail(DIA_E_ARG, "dia_enc_kv_prep: bad argument");
   hipLaunchKernelGGL(k_enc_kv_prep, dim3(heads, L), dim3(64), 0, (hipStream_t)stream, qkv, ldq, k_off, v_off, heads, L, cap, cos_t, sin_t, kc, vc);
   return dia_check_launch("k_enc_kv_prep");
+}
+
+extern "C" int dia_enc_attn(const dia_enc_attn_args* a, void* stream) {
+  if (!a || !a->qkv || !a->row_b || !a->seg_off || !a->seg_len || !a->cos_t || !a->sin_t || !a->kp || !a->vp || !a->P)
+    return dia_fail(DIA_E_ARG, "dia_enc_attn: null argument");
+  if (a->heads <= 0 || a->rows <= 0 || a->rows % 32 != 0) return dia_fail(DIA_E_ARG, "dia_enc_attn: rows must be a positive multiple of 32");
+  if (a->p_plane_stride % 8 != 0 || (a->heads * 128 + 31) / 32 > a->p_ktiles) return dia_fail(DIA_E_ARG, "dia_enc_attn: output planes too narrow");
+  EncAttnK k;
+  k.qkv = a->qkv; k.ldq = a->ldq; k.q_off = a->q_off; k.k_off = a->k_off; k.v_off = a->v_off; k.heads = a->heads; k.rows = a->rows;
+  k.row_b = a->row_b; k.seg_off = a->seg_off; k.seg_len = a->seg_len; k.cos_t = a->cos_t; k.sin_t = a->sin_t;
+  k.kp = (bf16_raw*)a->kp; k.vp = (bf16_raw*)a->vp; k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_enc_kv_planes, dim3(a->heads, a->rows / 32), dim3(256), 0, st, k);
+  int rc = dia_check_launch("k_enc_kv_planes");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_attn_enc_mfma, dim3(a->heads, a->rows / 16), dim3(NT), 0, st, k);
+  return dia_check_launch("k_attn_enc_mfma");
 }

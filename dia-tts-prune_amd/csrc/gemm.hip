@@ -61,6 +61,7 @@ struct GemmK {
   const int* cmap; const int* strip_map;
   float* sk_scratch; int* sk_tickets;     // cross-workgroup split-K (gridDim.y > 1)
   int kv_vblocked;
+  const int* row_b; const int* seg_off;   // CROSSKV over a packed batch
 };
 
 __device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v) {
@@ -143,10 +144,16 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
   } else {  // DIA_EPI_CROSSKV: strips [0, heads*8) hold K as RoPE pairs (d, d+64), the rest hold V
     if (!live) return;
     if (p.strip_map) strip = p.strip_map[strip];                  // compacted cross K/V: original strip index
+    int kvb = p.kv_batch_index;
+    if (p.row_b) {                                                // packed batch: row -> (utterance, position)
+      kvb = p.row_b[m];
+      if (kvb < 0) return;
+      m -= p.seg_off[kvb];
+    }
     const int nk = p.kv_heads * 8;
     if (strip < nk) {
       const int head = strip >> 3, i0 = (strip & 7) * 8 + half * 4;
-      const long base = (((long)p.kv_batch_index * p.kv_heads + head) * p.kv_cap + m) * 128;
+      const long base = (((long)kvb * p.kv_heads + head) * p.kv_cap + m) * 128;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int i = i0 + t;
@@ -158,12 +165,12 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
     } else {
       const int sv = strip - nk, head = sv >> 3, d0 = (sv & 7) * 16 + half * 8;
       if (p.kv_vblocked) {      // [key/32][128 dims][32 keys] (MFMA attention reads 8 consecutive keys per lane)
-        const long hb = ((long)p.kv_batch_index * p.kv_heads + head) * p.kv_cap * 128;
+        const long hb = ((long)kvb * p.kv_heads + head) * p.kv_cap * 128;
         const long blk = hb + (long)(m >> 5) * 128 * 32 + (m & 31);
 #pragma unroll
         for (int j = 0; j < 8; ++j) kv_store(p.vc, p.kv_dtype, blk + (long)(d0 + j) * 32, trow[half * 8 + j] * inv);
       } else {
-        const long base = (((long)p.kv_batch_index * p.kv_heads + head) * p.kv_cap + m) * 128 + d0;
+        const long base = (((long)kvb * p.kv_heads + head) * p.kv_cap + m) * 128 + d0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) kv_store(p.vc, p.kv_dtype, base + j, trow[half * 8 + j] * inv);
       }
@@ -887,7 +894,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
     return dia_fail(DIA_E_ARG, "dia_gemm: RESID_EMIT needs planes and ssq_out covering N");
   if ((a->epi == DIA_EPI_SWIGLU_EMIT) && (!a->P || a->p_ktiles * 32 < a->nstrips * 8))
     return dia_fail(DIA_E_ARG, "dia_gemm: SWIGLU_EMIT needs planes covering N/2");
-  if (a->epi == DIA_EPI_CROSSKV && (!a->kc || !a->vc || !a->cos_t || !a->sin_t || (!a->strip_map && a->nstrips != a->kv_heads * 16) || a->M > a->kv_cap || (a->kv_vblocked && a->kv_cap % 32 != 0)))
+  if (a->epi == DIA_EPI_CROSSKV && (!a->kc || !a->vc || !a->cos_t || !a->sin_t || (!a->strip_map && a->nstrips != a->kv_heads * 16) || (!a->row_b && a->M > a->kv_cap) || (!a->row_b != !a->seg_off) || (a->kv_vblocked && a->kv_cap % 32 != 0)))
     return dia_fail(DIA_E_ARG, "dia_gemm: CROSSKV shape mismatch");
   if (a->epi < 0 || a->epi > DIA_EPI_CROSSKV) return dia_fail(DIA_E_ARG, "dia_gemm: unknown epilogue");
   if (a->ssq_in && a->ssq_ld < ((a->M + 15) / 16) * 16) return dia_fail(DIA_E_ARG, "dia_gemm: ssq_ld smaller than padded rows");
@@ -902,6 +909,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   k.kv_batch_index = a->kv_batch_index; k.cos_t = a->cos_t; k.sin_t = a->sin_t; k.spw = a->spw;
   k.cmap = a->cmap; k.strip_map = a->strip_map;
   k.sk_scratch = a->sk_scratch; k.sk_tickets = a->sk_tickets; k.kv_vblocked = a->kv_vblocked;
+  k.row_b = a->row_b; k.seg_off = a->seg_off;
 
   int nw = a->nw;
   if (nw == 0) {

@@ -20,7 +20,7 @@ EPI_SCALE_STORE, EPI_RESID_EMIT, EPI_SWIGLU_EMIT, EPI_CROSSKV = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
 
 EXPORTS = (
-    "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_gemm_timed", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep",
+    "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_gemm_timed", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep", "dia_enc_attn",
     "dia_embed_text", "dia_embed_tokens", "dia_sample", "dia_prefetch", "dia_engine_create", "dia_engine_destroy",
     "dia_engine_decode", "dia_engine_set_prefetch", "dia_engine_step_logits_only", "dia_engine_profile_step", "dia_engine_launches_per_step",
 )
@@ -42,6 +42,7 @@ class GemmArgs(C.Structure):
         ("kv_batch_index", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("cmap", C.c_void_p), ("strip_map", C.c_void_p),
         ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p), ("sk", C.c_int32), ("kv_vblocked", C.c_int32),
+        ("row_b", C.c_void_p), ("seg_off", C.c_void_p),
     ]
 
 
@@ -55,6 +56,16 @@ class AttnArgs(C.Structure):
         ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("_pad1", C.c_int32),
         ("scratch", C.c_void_p), ("tickets", C.c_void_p), ("head_map", C.c_void_p),
         ("v_blocked", C.c_int32), ("_pad2", C.c_int32),
+    ]
+
+
+class EncAttnArgs(C.Structure):
+    _fields_ = [
+        ("qkv", C.c_void_p), ("ldq", C.c_int32), ("q_off", C.c_int32), ("k_off", C.c_int32), ("v_off", C.c_int32),
+        ("heads", C.c_int32), ("rows", C.c_int32),
+        ("row_b", C.c_void_p), ("seg_off", C.c_void_p), ("seg_len", C.c_void_p), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
+        ("kp", C.c_void_p), ("vp", C.c_void_p), ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32),
+        ("_pad0", C.c_int32),
     ]
 
 
@@ -145,6 +156,7 @@ def lib() -> C.CDLL:
     L.dia_gemm_timed.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.POINTER(C.c_float)]
     L.dia_attn.argtypes = [C.POINTER(AttnArgs), C.c_void_p]
     L.dia_attn_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.dia_enc_attn.argtypes = [C.POINTER(EncAttnArgs), C.c_void_p]
     L.dia_enc_kv_prep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dia_embed_text.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

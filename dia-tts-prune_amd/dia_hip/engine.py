@@ -378,11 +378,10 @@ class DecodeSession:
         Replaces model.py:382-397 (Encoder.forward layers.py:445-462; precompute_cross_attn_cache 632-669).
 
         All utterances run as ONE packed batch: utterance b occupies rows [off_b, off_b + L_b) of every
-        activation buffer, off_b a multiple of 16 (whole m-tiles), padding rows zero.  The dense layers
+        activation buffer, off_b a multiple of 32 (whole m-tiles and key blocks), padding rows zero.  The dense layers
         (qkv, o, wi, wo) are single GEMMs over all rows — weights are read once per batch and the row count
-        is what the MFMA-tiled kernel wants — while the per-utterance pieces (embedding, K/V prep, the
-        bidirectional attention, the cross-K/V projection with its RoPE positions) address their rows through
-        offset pointers.  Only the non-pad tokens of the cond row are computed (exact)."""
+        is what the MFMA-tiled kernel wants — and so are the bidirectional attention (dia_enc_attn) and the cross-K/V projection, which find a row's
+        utterance and RoPE position through row_b / seg_off; only the embedding runs per utterance.  Only the non-pad tokens of the cond row are computed (exact)."""
         L = hb.lib()
         cfg, w, dev = self.cfg, self.w, self.dev
         e, d = cfg.model.encoder, cfg.model.decoder
@@ -392,7 +391,7 @@ class DecodeSession:
         offs, tot = [], 0
         for Lb in self.lens:
             offs.append(tot)
-            tot += _ceil(Lb, 16)
+            tot += _ceil(Lb, 32)                     # whole 32-key blocks per utterance (blocked V planes)
         self.enc_out = [None] * self.B
         with torch.cuda.stream(self.stream):
             if tot > 0:
@@ -405,9 +404,14 @@ class DecodeSession:
                 ssq = z(E // 16, Mp)
                 nq = 3 * e.n_head * HEAD_DIM
                 qkv = z(Mp, nq)
-                kc, vc = z(e.n_head, Lmax, HEAD_DIM), z(e.n_head, Lmax, HEAD_DIM)
-                esc = z(max(1, L.dia_attn_scratch_floats(Lmax, e.n_head, Lmax)))
-                etk = z(Lmax * e.n_head, dt=torch.int32)
+                kp = z(3, e.n_head, Mp, HEAD_DIM, dt=torch.bfloat16)           # K / V planes of the attention (scratch)
+                vp = z(3, e.n_head, Mp, HEAD_DIM, dt=torch.bfloat16)
+                rb = np.full((Mp,), -1, dtype=np.int32)
+                for b, Lb in enumerate(self.lens):
+                    rb[offs[b]: offs[b] + Lb] = b
+                row_b = torch.from_numpy(rb).to(dev)
+                seg_off = torch.tensor(offs, dtype=torch.int32, device=dev)
+                seg_len = torch.tensor(self.lens, dtype=torch.int32, device=dev)
                 live = [b for b in range(self.B) if self.lens[b] > 0]
 
                 def rows(t, b, width):              # device pointer of row off_b of a [Mp, width] fp32 buffer
@@ -423,7 +427,7 @@ class DecodeSession:
                                               ssq.data_ptr() + offs[b] * 4, Mp, st), "dia_embed_text")
 
                 def gemm(A, a_kt, W: TiledW, epi, *, M=Mp, a_ptr=None, ssq_ptr=None, ssq_in=False, out=None, ldo=0, gnext=None,
-                         P=None, p_kt=0, ssq_out=False, kv=None, strip_map=None):
+                         P=None, p_kt=0, ssq_out=False, kv=None, strip_map=None, row_map=False):
                     g = hb.GemmArgs()
                     g.A, g.a_plane_stride, g.a_ktiles, g.M = (a_ptr if a_ptr is not None else hb.ptr(A)), A[0].numel(), a_kt, M
                     g.W, g.KT, g.nstrips, g.epi = hb.ptr(W.t), W.kt, W.ns, epi
@@ -442,34 +446,28 @@ class DecodeSession:
                     if kv is not None:
                         g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = kv
                         g.cos_t, g.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
+                    if row_map:
+                        g.row_b, g.seg_off = hb.ptr(row_b), hb.ptr(seg_off)
                     hb.check(L.dia_gemm(C.byref(g), st), "dia_gemm")
 
                 for i, EL in enumerate(w.enc_layers):
                     gemm(px, ekt, EL["qkv"], hb.EPI_SCALE_STORE, ssq_in=True, out=qkv, ldo=nq)
-                    for b in live:
-                        Lb = self.lens[b]
-                        qp = rows(qkv, b, nq)
-                        hb.check(L.dia_enc_kv_prep(qp, nq, e.n_head * HEAD_DIM, 2 * e.n_head * HEAD_DIM, e.n_head, Lb, Lmax,
-                                                   hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(kc), hb.ptr(vc), st), "dia_enc_kv_prep")
-                        a = hb.AttnArgs()
-                        a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_ENC, hb.KV_F32, e.n_head, 1, Lb, Lmax
-                        a.q, a.ldq, a.q_off = qp, nq, 0
-                        a.kc, a.vc, a.enc_len = hb.ptr(kc), hb.ptr(vc), Lb
-                        a.cos_t, a.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
-                        a.P, a.p_plane_stride, a.p_ktiles = planes_at(pa, b, akt), pa[0].numel(), akt
-                        a.scratch, a.tickets = hb.ptr(esc), hb.ptr(etk)
-                        hb.check(L.dia_attn(C.byref(a), st), "dia_attn(enc)")
+                    ea_ = hb.EncAttnArgs()
+                    ea_.qkv, ea_.ldq, ea_.q_off, ea_.k_off, ea_.v_off = hb.ptr(qkv), nq, 0, e.n_head * HEAD_DIM, 2 * e.n_head * HEAD_DIM
+                    ea_.heads, ea_.rows = e.n_head, Mp
+                    ea_.row_b, ea_.seg_off, ea_.seg_len = hb.ptr(row_b), hb.ptr(seg_off), hb.ptr(seg_len)
+                    ea_.cos_t, ea_.sin_t, ea_.kp, ea_.vp = hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(kp), hb.ptr(vp)
+                    ea_.P, ea_.p_plane_stride, ea_.p_ktiles = hb.ptr(pa), pa[0].numel(), akt
+                    hb.check(L.dia_enc_attn(C.byref(ea_), st), "dia_enc_attn")
                     gemm(pa, akt, EL["o"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=EL["g_mlp"], P=px, p_kt=ekt, ssq_out=True)
                     gemm(px, ekt, EL["wi"], hb.EPI_SWIGLU_EMIT, ssq_in=True, P=ph, p_kt=hkt)
                     gnext = w.enc_layers[i + 1]["g_sa"] if i + 1 < len(w.enc_layers) else w.enc_norm
                     gemm(ph, hkt, EL["wo"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=gnext, P=px, p_kt=ekt, ssq_out=True)
                 # px now holds planes(x * encoder.norm.weight); ssq the row sums of squares of x
                 for i, DL in enumerate(w.dec_layers):
-                    for b in live:
-                        gemm(px, ekt, DL["ckv"], hb.EPI_CROSSKV, M=self.lens[b], a_ptr=planes_at(px, b, ekt),
-                             ssq_ptr=ssq.data_ptr() + offs[b] * 4, ssq_in=True,
-                             kv=(hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i]), self.kv_code, d.cross_query_heads, self.S, b),
-                             strip_map=DL["smap_ckv"])
+                    gemm(px, ekt, DL["ckv"], hb.EPI_CROSSKV, ssq_in=True,
+                         kv=(hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i]), self.kv_code, d.cross_query_heads, self.S, 0),
+                         strip_map=DL["smap_ckv"], row_map=True)
                 if keep_encoder_out:
                     for b in live:
                         Lb, o = self.lens[b], offs[b]

@@ -102,6 +102,10 @@ typedef struct {
   int32_t* sk_tickets;
   int32_t sk;
   int32_t kv_vblocked;      /* CROSSKV: 1 = write V in the blocked layout of dia_attn_args.v_blocked (kv_cap % 32 == 0) */
+  /* CROSSKV over a packed prefill batch: row m belongs to utterance row_b[m] (-1 = padding, skipped) at text
+   * position m - seg_off[row_b[m]]; both NULL = one utterance, kv_batch_index, position m. */
+  const int32_t* row_b;
+  const int32_t* seg_off;
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
@@ -150,6 +154,30 @@ typedef struct {
 } dia_attn_args;
 int dia_attn(const dia_attn_args* a, void* stream);
 int dia_attn_scratch_floats(int n_rows, int n_kv_heads, int kv_cap);
+
+/* Encoder self-attention of a PACKED prefill batch (Encoder.forward, layers.py:385-462, for every utterance
+ * at once): utterance b owns packed rows [seg_off[b], seg_off[b] + seg_len[b]), seg_off a multiple of 32;
+ * row_b[m] = utterance of packed row m or -1 for padding.  Launches the K/V plane preparation and the
+ * MFMA attention; all arithmetic fp32-exact (three bf16 planes per operand).  kp / vp are scratch:
+ * 3 * heads * rows * 128 bf16 each. */
+typedef struct {
+  const float* qkv;         /* [rows][ldq] fp32: q head h at q_off + h*128, k at k_off + h*128, v at v_off + h*128 */
+  int32_t ldq, q_off, k_off, v_off;
+  int32_t heads;
+  int32_t rows;             /* packed rows, multiple of 32 */
+  const int32_t* row_b;     /* [rows] */
+  const int32_t* seg_off;   /* [B] */
+  const int32_t* seg_len;   /* [B] */
+  const float* cos_t;       /* [npos][64] */
+  const float* sin_t;
+  void* kp;                 /* scratch K planes */
+  void* vp;                 /* scratch V planes (blocked) */
+  void* P;                  /* output planes [3][rows/16][p_ktiles][64][8]; padding rows are not written */
+  int64_t p_plane_stride;
+  int32_t p_ktiles;
+  int32_t _pad0;
+} dia_enc_attn_args;
+int dia_enc_attn(const dia_enc_attn_args* a, void* stream);
 
 /* Encoder helper: RoPE(k) and v of all L tokens from the qkv rows into an fp32 [heads][cap][128]
  * scratch "cache" (layers.py:274-279,306-307 for the encoder). */

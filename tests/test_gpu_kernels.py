@@ -340,6 +340,55 @@ def test_attn_encoder_mode_and_kv_prep():
         assert (out[:, h] - ref).abs().max().item() <= 2e-5
 
 
+def test_enc_attn_packed_batch():
+    """dia_enc_attn: bidirectional attention of several utterances packed into one row range (prefill),
+    MFMA with three planes per operand, against float64 per utterance; padding rows stay untouched."""
+    d = dev()
+    torch.manual_seed(9)
+    H, lens = 4, [45, 32, 0, 70, 1]
+    offs, tot = [], 0
+    for Lb in lens:
+        offs.append(tot); tot += (Lb + 31) // 32 * 32
+    nq = 3 * H * 128
+    qkv = torch.randn(tot, nq, device=d)
+    cos, sin = [t.to(d) for t in lay.rope_tables(128, 128, 1, 10000)]
+    rb = np.full((tot,), -1, dtype=np.int32)
+    for b, Lb in enumerate(lens):
+        rb[offs[b]: offs[b] + Lb] = b
+    row_b = torch.from_numpy(rb).to(d)
+    seg_off = torch.tensor(offs, dtype=torch.int32, device=d); seg_len = torch.tensor(lens, dtype=torch.int32, device=d)
+    kp = torch.zeros(3, H, tot, 128, dtype=torch.bfloat16, device=d); vp = torch.zeros_like(kp)
+    sentinel = 7.0
+    P = lay.pack_planes(torch.full((tot, H * 128), sentinel, device=d))
+    a = hb.EncAttnArgs()
+    a.qkv, a.ldq, a.q_off, a.k_off, a.v_off, a.heads, a.rows = hb.ptr(qkv), nq, 0, H * 128, 2 * H * 128, H, tot
+    a.row_b, a.seg_off, a.seg_len, a.cos_t, a.sin_t = hb.ptr(row_b), hb.ptr(seg_off), hb.ptr(seg_len), hb.ptr(cos), hb.ptr(sin)
+    a.kp, a.vp, a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(kp), hb.ptr(vp), hb.ptr(P), P[0].numel(), P.shape[2]
+    hb.check(hb.lib().dia_enc_attn(C.byref(a), None), "dia_enc_attn")
+    torch.cuda.synchronize()
+    out = lay.unpack_planes(P, tot, H * 128).double().reshape(tot, H, 128)
+    worst = 0.0
+    for b, Lb in enumerate(lens):
+        if Lb == 0:
+            continue
+        o = offs[b]
+        c, s_ = cos[:Lb].double()[:, None], sin[:Lb].double()[:, None]
+        rope = lambda x: torch.cat([x[..., :64] * c - x[..., 64:] * s_, x[..., :64] * s_ + x[..., 64:] * c], dim=-1)
+        q = rope(qkv[o: o + Lb, : H * 128].double().reshape(Lb, H, 128))
+        k = rope(qkv[o: o + Lb, H * 128: 2 * H * 128].double().reshape(Lb, H, 128))
+        v = qkv[o: o + Lb, 2 * H * 128:].double().reshape(Lb, H, 128)
+        for h in range(H):
+            worst = max(worst, (out[o: o + Lb, h] - attn_ref(q[:, h], k[:, h], v[:, h])).abs().max().item())
+    assert worst <= 2e-5, worst
+    pad = torch.from_numpy(rb < 0).to(d)
+    assert (out[pad] == sentinel).all()                       # padding rows are not written
+    # the three planes reproduce fp32 K exactly (k rows of utterance 0, head 1)
+    kk = (kp[0].float() + kp[1].float() + kp[2].float())[1, : lens[0]]
+    c, s_ = cos[: lens[0]], sin[: lens[0]]
+    x = qkv[: lens[0], H * 128 + 128: H * 128 + 256]
+    assert (kk.double() - torch.cat([x[:, :64] * c - x[:, 64:] * s_, x[:, :64] * s_ + x[:, 64:] * c], dim=-1).double()).abs().max().item() <= 1e-6
+
+
 def _sampler_session(B, T, C_, V, D, logits_rows, noise, *, temperature, top_p, top_k, cfg_scale=0.0, cur=1,
                      teacher=0, ignore_eos=0, max_tokens=None, tokens=None, fsm=None, delay=None):
     d = dev()
