@@ -571,65 +571,73 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
 // ---------------------------------------------------------------------------------------------------
 // Prefill GEMM (encoder layers, cross-K/V projections: M = text bytes, tens to thousands of rows).
 // Here the contraction is dense and MFMA is the roofline, not HBM: a workgroup owns a 64-row x 256-column
-// output block, 8 waves x (2 strips of 16 columns) x (4 m-tiles), each wave running the WHOLE K loop for
-// its strips (no cross-wave reduction).  The activation planes of the 64 rows (3 planes x 4 m-tiles x
-// 1 KiB per k-tile) are staged through LDS in chunks of 2 k-tiles, double-buffered, loaded two chunks
-// ahead; every A fragment read from LDS feeds two MFMAs (one per strip), which balances LDS read time
-// (12 x 1 KiB per k-tile and wave) against MFMA time (24 x 16 cycles).  Weight tiles come straight from
-// global memory into the B operand registers, four chunks (8 k-tiles) ahead; row groups of the same
-// column block re-read them from L2.  fp32-exact like every other GEMM here: 3 planes x bf16 weights.
+// output block; its 8 waves form a 2 x 4 grid, each wave = 2 m-tiles x 4 strips of 16 columns, running the
+// WHOLE K loop for its sub-block (no cross-wave reduction).  The activation planes of the 64 rows
+// (3 planes x 4 m-tiles x 1 KiB per k-tile) are staged through LDS in chunks of GT_KC k-tiles,
+// double-buffered, loaded two chunks ahead; every A fragment read from LDS feeds FOUR MFMAs (one per
+// strip), so LDS read time (6 KiB per k-tile and wave) is half the MFMA time (24 x 16 cycles) — with two
+// strips per fragment the two were equal and the kernel ran at a third of the MFMA bound.  Weight tiles come
+// straight from global memory into the B operand registers, PD chunks ahead; the two wave rows and the row
+// groups of the same column block re-read them from L2.  fp32-exact like every other GEMM here: 3 planes
+// x bf16 weights.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // plain vector: HIP's uint4 struct defeats SROA in register arrays
-constexpr int GT_NW = 8, GT_MT = 4, GT_KC = 2, GT_NT = GT_NW * 64;
-constexpr size_t GT_ABUF = (size_t)GT_KC * DIA_NPLANES * GT_MT * 64 * 16;     // bytes of one staged chunk (24 KiB)
+constexpr int GT_NW = 8, GT_MT = 4, GT_NT = GT_NW * 64, GT_WM = 2, GT_WS = 4;   // per wave: 2 m-tiles x 4 strips
+constexpr size_t gt_abuf(int kc) { return (size_t)kc * DIA_NPLANES * GT_MT * 64 * 16; }    // bytes of one staged chunk (24 KiB at 2 k-tiles)
+constexpr size_t gt_smem(int kc) { return 2 * gt_abuf(kc) + sizeof(float) * (GT_NW * 2 * 16 * 17 + 64); }
 
-__global__ __launch_bounds__(GT_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_tile(GemmK p) {
+// GT_KC k-tiles per staged chunk, weight tiles PD chunks ahead, WPE waves per SIMD (2 = one workgroup per CU)
+template <int GT_KC, int PD, int WPE>
+__global__ __launch_bounds__(GT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_gemm_tile(GemmK p) {
+  constexpr size_t GT_ABUF = gt_abuf(GT_KC);
+  constexpr int NPIECE = GT_KC * DIA_NPLANES * GT_MT * 64 / GT_NT;     // 16-byte pieces per thread and chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* abuf = reinterpret_cast<u32x4*>(smem_raw);                                     // [2][KC][3][MT][64] x 16 B
   float* tiles = reinterpret_cast<float*>(smem_raw + 2 * GT_ABUF);                      // [NW][2][16][17]
   float* inv_s = tiles + GT_NW * 2 * 16 * 17;                                           // [64]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 2, wc = w & 3;                                                    // wave row (m-tiles 2wr, 2wr+1), wave column
   const int mt0 = blockIdx.y * GT_MT;
   const int mtiles = (p.M + 15) >> 4;
-  const int s0 = blockIdx.x * (GT_NW * 2) + w * 2;
-  const int sl0 = min(s0, p.nstrips - 1), sl1 = min(s0 + 1, p.nstrips - 1);            // clamped for the loads
+  const int s0 = blockIdx.x * (GT_NW * 2) + wc * GT_WS;
   const int nchunks = p.KT / GT_KC;                                                     // KT % 8 == 0 (dispatcher)
 
-  // ---- A staging: 1536 16-byte pieces per chunk, 3 per thread: piece -> (k-tile, plane, m-tile, lane)
-  const u32x4* asrc[3];
-  int adst[3];
+  // ---- A staging: pieces of 16 bytes, NPIECE per thread: piece -> (k-tile, plane, m-tile, lane)
+  const u32x4* asrc[NPIECE];
+  int adst[NPIECE];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < NPIECE; ++j) {
     const int i = tid + GT_NT * j;
     const int ln = i & 63, blk = i >> 6, mt = blk & 3, pl = (blk >> 2) % 3, kk = blk / 12;
     const int mtile = min(mt0 + mt, mtiles - 1);
     asrc[j] = reinterpret_cast<const u32x4*>(p.A + pl * p.a_plane_stride + (((long)mtile * p.a_ktiles + kk) * 64 + ln) * 8);
     adst[j] = ((kk * DIA_NPLANES + pl) * GT_MT + mt) * 64 + ln;
   }
-  auto a_load = [&](u32x4 (&r)[3], int chunk) {
+  auto a_load = [&](u32x4 (&r)[NPIECE], int chunk) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) r[j] = asrc[j][(long)chunk * GT_KC * 64];               // k-tile stride = 64 pieces
+    for (int j = 0; j < NPIECE; ++j) r[j] = asrc[j][(long)chunk * GT_KC * 64];          // k-tile stride = 64 pieces
   };
-  auto a_store = [&](const u32x4 (&r)[3], int buf) {
+  auto a_store = [&](const u32x4 (&r)[NPIECE], int buf) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) abuf[buf * (GT_ABUF / 16) + adst[j]] = r[j];
+    for (int j = 0; j < NPIECE; ++j) abuf[buf * (GT_ABUF / 16) + adst[j]] = r[j];
   };
-  const bf16x8* W0 = reinterpret_cast<const bf16x8*>(p.W) + (long)sl0 * p.KT * 64 + lane;
-  const bf16x8* W1 = reinterpret_cast<const bf16x8*>(p.W) + (long)sl1 * p.KT * 64 + lane;
-  auto b_load = [&](bf16x8 (&b)[GT_KC][2], int chunk) {
+  const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + lane;
+  long woff[GT_WS];
 #pragma unroll
-    for (int kk = 0; kk < GT_KC; ++kk) {
-      b[kk][0] = W0[(long)(chunk * GT_KC + kk) * 64];
-      b[kk][1] = W1[(long)(chunk * GT_KC + kk) * 64];
-    }
+  for (int j = 0; j < GT_WS; ++j) woff[j] = (long)min(s0 + j, p.nstrips - 1) * p.KT * 64;   // clamped for the loads
+  auto b_load = [&](bf16x8 (&b)[GT_KC][GT_WS], int chunk) {
+#pragma unroll
+    for (int kk = 0; kk < GT_KC; ++kk)
+#pragma unroll
+      for (int j = 0; j < GT_WS; ++j) b[kk][j] = Wl[woff[j] + (long)(chunk * GT_KC + kk) * 64];
   };
 
-  u32x4 areg0[3], areg1[3];
-  bf16x8 bq[4][GT_KC][2];
+  u32x4 areg0[NPIECE], areg1[NPIECE];
+  bf16x8 bq[PD][GT_KC][GT_WS];
   a_load(areg0, 0);
   if (nchunks > 1) a_load(areg1, 1);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) if (j < nchunks) b_load(bq[j], j);
+  for (int j = 0; j < PD; ++j) if (j < nchunks) b_load(bq[j], j);
 
   // RMSNorm scale of the 64 rows (8 threads per row sum the strip partials in fixed order)
   {
@@ -645,14 +653,14 @@ __global__ __launch_bounds__(GT_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   a_store(areg0, 0);
   __syncthreads();
 
-  f32x4 acc[2][GT_MT];
+  f32x4 acc[GT_WM][GT_WS];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int i = 0; i < GT_WM; ++i)
 #pragma unroll
-    for (int mt = 0; mt < GT_MT; ++mt) acc[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < GT_WS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto chunk_body = [&](int c, auto Q) {
-    constexpr int q = decltype(Q)::value;           // q = c & 3, a literal at every call: buffer parities are compile-time
+    constexpr int q = decltype(Q)::value;           // q = c mod PD, a literal at every call: buffer parities are compile-time
     if (c + 2 < nchunks) { if constexpr ((q & 1) == 0) a_load(areg0, c + 2); else a_load(areg1, c + 2); }
     const u32x4* ab = abuf + (q & 1) * (GT_ABUF / 16);
 #pragma unroll
@@ -660,61 +668,76 @@ __global__ __launch_bounds__(GT_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
       for (int pl = 0; pl < DIA_NPLANES; ++pl)
 #pragma unroll
-        for (int mt = 0; mt < GT_MT; ++mt) {
-          const u32x4 av = ab[((kk * DIA_NPLANES + pl) * GT_MT + mt) * 64 + lane];
+        for (int i = 0; i < GT_WM; ++i) {
+          const u32x4 av = ab[((kk * DIA_NPLANES + pl) * GT_MT + wr * GT_WM + i) * 64 + lane];
           const bf16x8 a = __builtin_bit_cast(bf16x8, av);
-          acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[q][kk][0], acc[0][mt], 0, 0, 0);
-          acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[q][kk][1], acc[1][mt], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < GT_WS; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[q][kk][j], acc[i][j], 0, 0, 0);
         }
-    if (c + 4 < nchunks) b_load(bq[q], c + 4);
+    if (c + PD < nchunks) b_load(bq[q], c + PD);
     if (c + 1 < nchunks) { if constexpr ((q & 1) == 0) a_store(areg1, 1); else a_store(areg0, 0); }
     lds_barrier();
   };
-  for (int c0 = 0; c0 < nchunks; c0 += 4) {
+  static_assert(PD == 2 || PD == 4, "ring depth");
+  for (int c0 = 0; c0 < nchunks; c0 += PD) {
     chunk_body(c0, std::integral_constant<int, 0>{});
     if (c0 + 1 < nchunks) chunk_body(c0 + 1, std::integral_constant<int, 1>{});
-    if (c0 + 2 < nchunks) chunk_body(c0 + 2, std::integral_constant<int, 2>{});
-    if (c0 + 3 < nchunks) chunk_body(c0 + 3, std::integral_constant<int, 3>{});
+    if constexpr (PD == 4) {
+      if (c0 + 2 < nchunks) chunk_body(c0 + 2, std::integral_constant<int, 2>{});
+      if (c0 + 3 < nchunks) chunk_body(c0 + 3, std::integral_constant<int, 3>{});
+    }
   }
 
-  // ---- epilogue, per wave: the two 16x16 tiles of an m-tile at a time through this wave's LDS tiles
+  // ---- epilogue, per wave: two 16x16 tiles (a strip pair of one m-tile) at a time through this wave's LDS tiles
   float* tw = tiles + w * (2 * 16 * 17);
   const int et = lane >> 5, e_r = (lane >> 1) & 15, half = lane & 1;
-  const int strip = s0 + et;
   const int col = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
-  for (int mt = 0; mt < GT_MT; ++mt) {
+  for (int i = 0; i < GT_WM; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int pr = 0; pr < GT_WS / 2; ++pr) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tw[j * (16 * 17) + (r0 + r) * 17 + col] = acc[j][mt][r];
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int m = (mt0 + mt) * 16 + e_r;
-    const bool live = m < p.M && strip < p.nstrips;
-    const int n0 = strip * 16 + half * 8;
-    float xpre[8], gpre[8];
-    if (p.epi == DIA_EPI_RESID_EMIT && live) {
-      const float* o = p.out + (long)m * p.ldo + n0;
-      const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
-      xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
-      xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) gpre[jj] = p.gnext ? p.gnext[n0 + jj] : 1.0f;
+        for (int r = 0; r < 4; ++r) tw[j * (16 * 17) + (r0 + r) * 17 + col] = acc[i][2 * pr + j][r];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int mtl = wr * GT_WM + i;
+      const int m = (mt0 + mtl) * 16 + e_r;
+      const int strip = s0 + 2 * pr + et;
+      const bool live = m < p.M && strip < p.nstrips;
+      const int n0 = strip * 16 + half * 8;
+      float xpre[8], gpre[8];
+      if (p.epi == DIA_EPI_RESID_EMIT && live) {
+        const float* o = p.out + (long)m * p.ldo + n0;
+        const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+        xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+        xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) gpre[jj] = p.gnext ? p.gnext[n0 + jj] : 1.0f;
+      }
+      run_epilogue(p, tw + et * (16 * 17) + e_r * 17, inv_s[mtl * 16 + e_r], m, n0, half, min(strip, p.nstrips - 1), live, xpre, gpre);
+      __builtin_amdgcn_wave_barrier();
     }
-    run_epilogue(p, tw + et * (16 * 17) + e_r * 17, inv_s[mt * 16 + e_r], m, n0, half, min(strip, p.nstrips - 1), live, xpre, gpre);
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
-constexpr size_t GT_SMEM = 2 * GT_ABUF + sizeof(float) * (GT_NW * 2 * 16 * 17 + 64);
+template <int KC, int PD, int WPE>
+int launch_tile_v(const GemmK& k, hipStream_t st) {
+  const int mgroups = ((k.M + 15) / 16 + GT_MT - 1) / GT_MT;
+  launch_kernel(k_gemm_tile<KC, PD, WPE>, dim3((k.nstrips + GT_NW * 2 - 1) / (GT_NW * 2), mgroups), dim3(GT_NT), gt_smem(KC), st, k);
+  return dia_check_launch("k_gemm_tile");
+}
 
 int launch_tile(const GemmK& k, hipStream_t st) {
   int rc = dia_kernels_init_once();
   if (rc) return rc;
-  const int mgroups = ((k.M + 15) / 16 + GT_MT - 1) / GT_MT;
-  launch_kernel(k_gemm_tile, dim3((k.nstrips + GT_NW * 2 - 1) / (GT_NW * 2), mgroups), dim3(GT_NT), GT_SMEM, st, k);
-  return dia_check_launch("k_gemm_tile");
+  int v = 0;
+  if (const char* e = getenv("DIA_DBG_TILE_V")) v = atoi(e);
+  if (v == 1) return launch_tile_v<2, 2, 4>(k, st);
+  if (v == 2 && k.KT % 16 == 0) return launch_tile_v<4, 2, 2>(k, st);
+  return launch_tile_v<2, 4, 2>(k, st);
 }
 
 template <int NW, int KPW>
@@ -876,7 +899,9 @@ extern "C" int dia_dbg_stamps(long long* host, int n) {
 // large-LDS attribute of every small-M instantiation, set once outside any graph capture
 int dia_gemm_init() {
   int rc = 0;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GT_SMEM) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(4)) != hipSuccess) rc = 1;
   rc |= small_attr<4, 4>(); rc |= small_attr<4, 8>(); rc |= small_attr<4, 16>();
   rc |= small_attr<8, 2>(); rc |= small_attr<8, 3>(); rc |= small_attr<8, 4>(); rc |= small_attr<8, 5>(); rc |= small_attr<8, 6>(); rc |= small_attr<8, 7>(); rc |= small_attr<8, 8>(); rc |= small_attr<8, 16>(); rc |= small_attr<8, 32>();
   rc |= small_attr<16, 1>(); rc |= small_attr<16, 2>(); rc |= small_attr<16, 4>(); rc |= small_attr<16, 8>();

@@ -16,6 +16,7 @@ a = ap.parse_args()
 d = torch.device("cuda:0")
 K, N, epi = {"wi": (2048, 16384, hb.EPI_SWIGLU_EMIT), "wo": (8192, 2048, hb.EPI_RESID_EMIT), "o": (2048, 2048, hb.EPI_RESID_EMIT),
              "qkv": (2048, 3072, hb.EPI_SCALE_STORE), "logits": (2048, 9264, hb.EPI_SCALE_STORE),
+             "eqkv": (1024, 3072, hb.EPI_SCALE_STORE), "eo": (1024, 1024, hb.EPI_RESID_EMIT), "ewi": (1024, 8192, hb.EPI_SWIGLU_EMIT), "ewo": (4096, 1024, hb.EPI_RESID_EMIT),
              "qkvp": (1024, 3072, hb.EPI_SCALE_STORE), "op": (1024, 2048, hb.EPI_RESID_EMIT), "wip": (1024, 8192, hb.EPI_SWIGLU_EMIT), "wop": (4096, 2048, hb.EPI_RESID_EMIT)}[a.shape]
 M = a.M
 mpad = (M + 15) // 16 * 16
@@ -54,4 +55,4 @@ for _ in range(a.reps):
         launch(W)
 e1.record(st); st.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / (a.reps * 18)
-print(f"{a.shape} M={M} nw={a.nw}: {us:.2f} us/launch (back-to-back incl. gaps), {K*N*2/us/1e3:.0f} GB/s")
+print(f"{a.shape} M={M} nw={a.nw}: {us:.2f} us/launch (back-to-back incl. gaps), {K*N*2/us/1e3:.0f} GB/s, {2*M*K*N/us/1e6:.1f} TFLOP/s algorithmic (x3 planes on the MFMA pipe)")
