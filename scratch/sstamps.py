@@ -6,8 +6,8 @@ from dia_hip.engine import DecodeSession, DeviceWeights
 from dia_hip.tokens import effective_text, encode_text
 from dia_hip.weights import synthetic_state_dict
 L = hb.lib(); L.dia_dbg_sstamps.argtypes = [C.c_void_p]
-cfg = Cf.mid_config()
-w = DeviceWeights(cfg, synthetic_state_dict(cfg, 1234, 0.02), torch.device("cuda:0"))
+cfg = Cf.dia_1_6b_config() if len(sys.argv) > 1 else Cf.mid_config()
+w = DeviceWeights(cfg, synthetic_state_dict(cfg, 1234, 0.02, device=torch.device("cuda:0")), torch.device("cuda:0"))
 s = DecodeSession(w, [encode_text(effective_text("[S1] hello there. [S2] hi"), cfg)], kv_dtype="bf16", max_tokens=64, seeds=[1], ignore_eos=True)
 s.prefill(); s.decode(30, use_graph=False); s.sync()
 buf = np.zeros(16, dtype=np.int64)
