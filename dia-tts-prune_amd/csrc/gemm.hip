@@ -581,14 +581,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
 // groups of the same column block re-read them from L2.  fp32-exact like every other GEMM here: 3 planes
 // x bf16 weights.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // plain vector: HIP's uint4 struct defeats SROA in register arrays
-constexpr int GT_NW = 8, GT_MT = 4, GT_NT = GT_NW * 64, GT_WM = 2, GT_WS = 4;   // per wave: 2 m-tiles x 4 strips
+constexpr int GT_MT = 4, GT_WM = 2, GT_WS = 4;   // workgroup: 4 m-tiles; per wave: 2 m-tiles x 4 strips
 constexpr size_t gt_abuf(int kc) { return (size_t)kc * DIA_NPLANES * GT_MT * 64 * 16; }    // bytes of one staged chunk (24 KiB at 2 k-tiles)
-constexpr size_t gt_smem(int kc) { return 2 * gt_abuf(kc) + sizeof(float) * (GT_NW * 2 * 16 * 17 + 64); }
+constexpr size_t gt_smem(int kc, int nw) { return 2 * gt_abuf(kc) + sizeof(float) * (nw * 2 * 16 * 17 + 64); }
 
 // GT_KC k-tiles per staged chunk, weight tiles PD chunks ahead, WPE waves per SIMD (2 = one workgroup per CU)
-template <int GT_KC, int PD, int WPE>
-__global__ __launch_bounds__(GT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_gemm_tile(GemmK p) {
+template <int GT_KC, int PD, int WPE, int GT_NW>
+__global__ __launch_bounds__(GT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_gemm_tile(GemmK p) {
   constexpr size_t GT_ABUF = gt_abuf(GT_KC);
+  constexpr int GT_NT = GT_NW * 64, GT_WC = GT_NW / 2;                 // wave grid 2 x GT_WC
   constexpr int NPIECE = GT_KC * DIA_NPLANES * GT_MT * 64 / GT_NT;     // 16-byte pieces per thread and chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* abuf = reinterpret_cast<u32x4*>(smem_raw);                                     // [2][KC][3][MT][64] x 16 B
@@ -596,10 +597,10 @@ __global__ __launch_bounds__(GT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
   float* inv_s = tiles + GT_NW * 2 * 16 * 17;                                           // [64]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wr = w >> 2, wc = w & 3;                                                    // wave row (m-tiles 2wr, 2wr+1), wave column
+  const int wr = w / GT_WC, wc = w % GT_WC;                                                    // wave row (m-tiles 2wr, 2wr+1), wave column
   const int mt0 = blockIdx.y * GT_MT;
   const int mtiles = (p.M + 15) >> 4;
-  const int s0 = blockIdx.x * (GT_NW * 2) + wc * GT_WS;
+  const int s0 = blockIdx.x * (GT_WC * GT_WS) + wc * GT_WS;
   const int nchunks = p.KT / GT_KC;                                                     // KT % 8 == 0 (dispatcher)
 
   // ---- A staging: pieces of 16 bytes, NPIECE per thread: piece -> (k-tile, plane, m-tile, lane)
@@ -640,8 +641,8 @@ __global__ __launch_bounds__(GT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
   for (int j = 0; j < PD; ++j) if (j < nchunks) b_load(bq[j], j);
 
   // RMSNorm scale of the 64 rows (8 threads per row sum the strip partials in fixed order)
-  {
-    const int r = tid >> 3, part = tid & 7, row = mt0 * 16 + r;
+  for (int t = tid; t < 64 * 8; t += GT_NT) {
+    const int r = t >> 3, part = t & 7, row = mt0 * 16 + r;
     float sA = 0.f;
     if (p.ssq_in != nullptr && row < p.M)
       for (int i = part; i < p.ssq_in_n; i += 8) sA += p.ssq_in[(long)i * p.ssq_ld + row];
@@ -723,21 +724,25 @@ __global__ __launch_bounds__(GT_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
   }
 }
 
-template <int KC, int PD, int WPE>
+template <int KC, int PD, int WPE, int NWT>
 int launch_tile_v(const GemmK& k, hipStream_t st) {
   const int mgroups = ((k.M + 15) / 16 + GT_MT - 1) / GT_MT;
-  launch_kernel(k_gemm_tile<KC, PD, WPE>, dim3((k.nstrips + GT_NW * 2 - 1) / (GT_NW * 2), mgroups), dim3(GT_NT), gt_smem(KC), st, k);
+  constexpr int SPB = (NWT / 2) * GT_WS;                 // strips per workgroup
+  launch_kernel(k_gemm_tile<KC, PD, WPE, NWT>, dim3((k.nstrips + SPB - 1) / SPB, mgroups), dim3(NWT * 64), gt_smem(KC, NWT), st, k);
   return dia_check_launch("k_gemm_tile");
 }
 
 int launch_tile(const GemmK& k, hipStream_t st) {
   int rc = dia_kernels_init_once();
   if (rc) return rc;
-  int v = 0;
+  // 8 waves / 64 x 256 blocks when they fill the chip (wi 137 vs 192 us at 1696 rows); narrow outputs (o, wo:
+  // N = 1024 -> 4 column blocks) get 4 waves / 64 x 128 blocks, twice the workgroups (wo 86 vs 97 us)
+  const int blocks8 = (((k.M + 15) / 16 + GT_MT - 1) / GT_MT) * ((k.nstrips + 15) / 16);
+  int v = blocks8 < 192 ? 1 : 0;
   if (const char* e = getenv("DIA_DBG_TILE_V")) v = atoi(e);
-  if (v == 1) return launch_tile_v<2, 2, 4>(k, st);
-  if (v == 2 && k.KT % 16 == 0) return launch_tile_v<4, 2, 2>(k, st);
-  return launch_tile_v<2, 4, 2>(k, st);
+  if (v == 1) return launch_tile_v<2, 4, 1, 4>(k, st);
+  if (v == 2) return launch_tile_v<2, 2, 1, 4>(k, st);
+  return launch_tile_v<2, 4, 2, 8>(k, st);
 }
 
 template <int NW, int KPW>
@@ -899,9 +904,9 @@ extern "C" int dia_dbg_stamps(long long* host, int n) {
 // large-LDS attribute of every small-M instantiation, set once outside any graph capture
 int dia_gemm_init() {
   int rc = 0;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2)) != hipSuccess) rc = 1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2)) != hipSuccess) rc = 1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(4)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 4, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 4, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 4)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 4)) != hipSuccess) rc = 1;
   rc |= small_attr<4, 4>(); rc |= small_attr<4, 8>(); rc |= small_attr<4, 16>();
   rc |= small_attr<8, 2>(); rc |= small_attr<8, 3>(); rc |= small_attr<8, 4>(); rc |= small_attr<8, 5>(); rc |= small_attr<8, 6>(); rc |= small_attr<8, 7>(); rc |= small_attr<8, 8>(); rc |= small_attr<8, 16>(); rc |= small_attr<8, 32>();
   rc |= small_attr<16, 1>(); rc |= small_attr<16, 2>(); rc |= small_attr<16, 4>(); rc |= small_attr<16, 8>();
@@ -982,7 +987,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   //   (only when the 64 x 256 blocks fill a good part of the chip: a lone short utterance is better off
   //   with the K-split kernels below)
   {
-    const int blocks = ((mtiles + GT_MT - 1) / GT_MT) * ((a->nstrips + GT_NW * 2 - 1) / (GT_NW * 2));
+    const int blocks = ((mtiles + GT_MT - 1) / GT_MT) * ((a->nstrips + 15) / 16);
     int min_blocks = 48;
     if (const char* e = getenv("DIA_DBG_TILE_MIN")) min_blocks = atoi(e);
     if (mtiles >= 3 && a->KT % 8 == 0 && !a->cmap && blocks >= min_blocks) return launch_tile(k, st);
