@@ -465,6 +465,231 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
 
 
 
+// ---------------------------------------------------------------------------------------------------
+// Fused SwiGLU MLP for M <= 2 rows (batch 1): wi_fused and wo in ONE persistent launch, the two phases
+// separated by a grid barrier.  What it buys: the weight stream never stops.  Between two separate launches
+// HBM idles for the tail of the first kernel (reduce + epilogue), the launch gap and the head of the
+// second (dispatch, operand staging, first-byte latency) — about 7 us per layer; here every workgroup
+// requests its share of the wo tiles BEFORE it arrives at the barrier, so the barrier's round trips are
+// covered by that stream.
+//   phase 1  = k_gemv_small<16, KPW1, 2, MULTI> with the SWIGLU epilogue; the hidden planes are written
+//              with device-coherent (sc1) stores
+//   barrier  = one relaxed agent-scope counter (stores acknowledged first, vmcnt 0), bounded spin
+//   phase 2  = k_gemv_small<16, KPW2, 2> with two workgroups per strip (split-K 2, fence-free combine) and
+//              the RESID_EMIT epilogue; the hidden planes are staged with sc1 loads
+// The grid (2 * wo strips = 256 workgroups of 16 waves, one per CU) must be fully resident: the host checks it
+// against the CU count; a spin that outlasts its bound raises an error word instead of hanging the GPU.
+// MEASURED (in-kernel stamps, Dia-1.6B shapes): it LOSES to the two launches, 37 vs 27 us.  Phase 1 ends at
+// 15 us (median), but the write-through stores of the hidden planes are acknowledged only at 17 us median /
+// 26 us worst under the saturating weight stream, the barrier completes 3.6 us after the last arrival and the
+// coherent re-read of the planes takes another 3.3 us.  A graph-replayed kernel boundary does the same hand-off
+// in about 5 us.  The kernel stays as a tested experiment (engine: DIA_MLP_FUSE=1), not as the default.
+struct MlpK { GemmK wi, wo; int* bar; };     // bar[0]: arrivals (monotonic, zeroed by the host per session), bar[1]: error flag
+
+__device__ __forceinline__ void st16_agent(bf16_raw* dst, bf16x8 v) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(&v);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst) + 1, q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bf16x8 ld16_agent(const bf16_raw* src) {
+  unsigned long long q[2];
+  q[0] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  q[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *reinterpret_cast<const bf16x8*>(q);
+}
+
+template <int KPW1, int KPW2>
+__global__ __launch_bounds__(1024) void k_mlp_fused(MlpK q) {
+  constexpr int NW = 16, RS = 2, NT = NW * 64;
+  constexpr int KT1 = NW * KPW1, KT2 = NW * KPW2;          // k-tiles of phase 1; k-tiles of ONE K half of phase 2
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][64]
+  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * 64);   // [16][17]
+  float* inv_s = tile + 16 * 17;                                           // [16]
+  bf16x8* As = reinterpret_cast<bf16x8*>(smem_raw + sizeof(f32x4) * NW * 64 + sizeof(float) * (16 * 17 + 16));
+  __shared__ int sk_flag;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int e_r = (tid >> 1) & 15, half = tid & 1, m = e_r;
+  const bool e_thread = tid < 32;
+  const int arow = min(lane & 15, RS - 1), akq = lane >> 4;
+  STAMP(0);
+
+  // phase 2's residual row and next-norm weight do not depend on phase 1: requested first (x is only written by
+  // the phase-2 epilogue)
+  const GemmK& p = q.wo;
+  const int strip2 = wg % p.nstrips, ks = wg / p.nstrips;     // two workgroups per strip: K halves
+  const bool live = e_thread && m < p.M;
+  float xpre[8], gpre[8];
+  if (e_thread) {
+    const int n0 = strip2 * 16 + half * 8;
+    const float* o = p.out + (long)(live ? m : 0) * p.ldo + n0;
+    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+    xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+    xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+    const float4 ga = *reinterpret_cast<const float4*>(p.gnext + n0), gb = *reinterpret_cast<const float4*>(p.gnext + n0 + 4);
+    gpre[0] = ga.x; gpre[1] = ga.y; gpre[2] = ga.z; gpre[3] = ga.w;
+    gpre[4] = gb.x; gpre[5] = gb.y; gpre[6] = gb.z; gpre[7] = gb.w;
+  }
+
+  // ================= phase 1: h = silu(gate) * up,  [gate|up] = norm(x) . wi =================
+  {
+    const GemmK& p = q.wi;
+    const bool live1 = e_thread && m < p.M;
+    const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + (long)(w * KPW1) * 64 + lane;
+    auto load_strip = [&](bf16x8 (&b)[KPW1], int strip) {
+      const bf16x8* Wt = Wl + (long)strip * p.KT * 64;
+#pragma unroll
+      for (int i = 0; i < KPW1; ++i) b[i] = DIA_WLOAD(Wt + (long)i * 64);
+    };
+    bf16x8 b0[KPW1], b1[KPW1];
+    constexpr int nch = DIA_NPLANES * KT1 * 4 * RS, CH = (nch + NT - 1) / NT;
+    bf16x8 v0[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int c = min(tid + u * NT, nch - 1);
+      const int row = c % RS, kq = (c / RS) & 3, kt = (c / (4 * RS)) % KT1, pl = c / (4 * RS * KT1);
+      v0[u] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)kt * 64 + row + 16 * kq) * 8);
+    }
+    const int s_row = tid >> 3, s_part = tid & 7;
+    float s0 = 0.f;
+    if (tid < 128 && s_row < p.M)
+      for (int i = s_part; i < p.ssq_in_n; i += 8) s0 += p.ssq_in[(long)i * p.ssq_ld + s_row];
+    __builtin_amdgcn_sched_barrier(0);
+    load_strip(b0, wg);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (tid + u * NT < nch) As[tid + u * NT] = v0[u];
+    s0 += __shfl_xor(s0, 1, 64);
+    s0 += __shfl_xor(s0, 2, 64);
+    s0 += __shfl_xor(s0, 4, 64);
+    if (tid < 128 && s_part == 0) inv_s[s_row] = rsqrtf(s0 * p.inv_d + p.eps);
+    lds_barrier();
+    auto body = [&](bf16x8 (&bc)[KPW1], bf16x8 (&bn)[KPW1], int strip) {
+      const int next = strip + G;
+      if (next < p.nstrips) load_strip(bn, next);
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int i = 0; i < KPW1; ++i)
+#pragma unroll
+        for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+          const bf16x8 a = As[((pl * KT1 + w * KPW1 + i) * 4 + akq) * RS + arow];
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bc[i], acc[0], 0, 0, 0);
+        }
+      reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
+      if (live1 && half == 0) {          // SWIGLU (layers.py:95-101): 8 gate columns then 8 up columns per strip
+        const float* trow = tile + e_r * 17;
+        const float inv = inv_s[e_r];
+        bf16x8 h, mi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float gte = trow[j] * inv, up = trow[8 + j] * inv;
+          const float v = (gte / (1.0f + expf(-gte))) * up;
+          __bf16 a, b, c;
+          split3(v, a, b, c);
+          h[j] = a; mi[j] = b; lo[j] = c;
+        }
+        const long off = plane_frag_off(m, strip * 8, p.p_ktiles);
+        st16_agent(p.P + off, h);
+        st16_agent(p.P + p.p_plane_stride + off, mi);
+        st16_agent(p.P + 2 * p.p_plane_stride + off, lo);
+      }
+    };
+    for (int strip = wg; strip < p.nstrips; strip += 2 * G) {
+      body(b0, b1, strip);
+      if (strip + G < p.nstrips) body(b1, b0, strip + G);
+    }
+  }
+
+  STAMP(1);
+  // ================= phase 2 weights: requested now, they stream while the barrier below completes =================
+  // (the hidden-plane stores of phase 1 are acknowledged first, so that the barrier's arrival needs no further wait)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bf16x8 b2[KPW2];
+  {
+    const bf16x8* Wt = reinterpret_cast<const bf16x8*>(p.W) + ((long)strip2 * p.KT + ks * KT2 + w * KPW2) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < KPW2; ++i) b2[i] = DIA_WLOAD(Wt + (long)i * 64);
+  }
+
+  // ================= grid barrier: every hidden plane is written (and acknowledged) before anyone reads =================
+  STAMP(2);
+  lds_barrier();                                     // every wave's stores are acknowledged (waited above); b2 stays in flight
+  if (tid == 0) {
+    const int v = __hip_atomic_fetch_add(q.bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int target = (v / G + 1) * G;              // arrivals of this launch complete the current multiple of G
+    int spins = 0;
+    while (__hip_atomic_load(q.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {
+      if (++spins > 400000) { __hip_atomic_store(q.bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  lds_barrier();
+
+  STAMP(3);
+  // ================= phase 2: x += h . wo (this workgroup: one K half of one strip) =================
+  {
+    constexpr int nch = DIA_NPLANES * KT2 * 4 * RS, CH = (nch + NT - 1) / NT;
+    bf16x8 v0[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int c = min(tid + u * NT, nch - 1);
+      const int row = c % RS, kq = (c / RS) & 3, kt = (c / (4 * RS)) % KT2, pl = c / (4 * RS * KT2);
+      v0[u] = ld16_agent(p.A + pl * p.a_plane_stride + ((long)(ks * KT2 + kt) * 64 + row + 16 * kq) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (tid + u * NT < nch) As[tid + u * NT] = v0[u];
+    if (tid < 16) inv_s[tid] = 1.0f;
+    lds_barrier();
+    STAMP(4);
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < KPW2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+        const bf16x8 a = As[((pl * KT2 + w * KPW2 + i) * 4 + akq) * RS + arow];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2[i], acc[0], 0, 0, 0);
+      }
+    reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
+    // split-K combine over the two K halves (fence-free slab hand-off, as splitk_combine)
+    const int SK = G / p.nstrips;
+    if (SK > 1) {
+      float* slab = p.sk_scratch + ((long)strip2 * SK + ks) * 256;
+      if (tid < 128) {
+        const int e = tid * 2;
+        st2_agent(slab + e, tile[(e >> 4) * 17 + (e & 15)], tile[(e >> 4) * 17 + (e & 15) + 1]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(p.sk_tickets + strip2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == SK - 1;
+        if (last) __hip_atomic_store(p.sk_tickets + strip2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sk_flag = last;
+      }
+      __syncthreads();
+      if (!sk_flag) return;
+      if (tid < 128) {
+        const int e = tid * 2;
+        const float* base = p.sk_scratch + (long)strip2 * SK * 256 + e;
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < SK; ++k) { const float2 v = ld2_agent(base + k * 256); a += v.x; b += v.y; }
+        tile[(e >> 4) * 17 + (e & 15)] = a; tile[(e >> 4) * 17 + (e & 15) + 1] = b;
+      }
+      __syncthreads();
+    }
+    if (e_thread) run_epilogue(p, tile + e_r * 17, 1.0f, m, strip2 * 16 + half * 8, half, strip2, live, xpre, gpre);
+    STAMP(5);
+  }
+}
+
+constexpr size_t mlp_smem(int kt1, int kt2) {
+  return sizeof(f32x4) * 16 * 64 + sizeof(float) * (16 * 17 + 16) + (size_t)DIA_NPLANES * (kt1 > kt2 ? kt1 : kt2) * 4 * 2 * 16;
+}
+
 // 5..16 rows (batch 3-8): one m-tile, A fragments held in registers for the workgroup's whole life
 // (each wave owns a fixed K range of KPW k-tiles = 12*KPW VGPRs) and reused for every strip the
 // workgroup walks; weight tiles double-buffered across strips like k_gemv_small.
@@ -901,9 +1126,25 @@ extern "C" int dia_dbg_stamps(long long* host, int n) {
 }
 #endif
 
+static int fill_gemmk(const dia_gemm_args* a, GemmK& k) {
+  k.A = (const bf16_raw*)a->A; k.a_plane_stride = a->a_plane_stride; k.a_ktiles = a->a_ktiles; k.M = a->M;
+  k.W = (const bf16_raw*)a->W; k.KT = a->KT; k.nstrips = a->nstrips; k.epi = a->epi;
+  k.ssq_in = a->ssq_in; k.ssq_in_n = a->ssq_in_n; k.ssq_ld = a->ssq_ld; k.inv_d = a->inv_d; k.eps = a->eps;
+  k.out = a->out; k.ldo = a->ldo; k.gnext = a->gnext;
+  k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles; k.ssq_out = a->ssq_out;
+  k.kc = a->kc; k.vc = a->vc; k.kv_dtype = a->kv_dtype; k.kv_heads = a->kv_heads; k.kv_cap = a->kv_cap;
+  k.kv_batch_index = a->kv_batch_index; k.cos_t = a->cos_t; k.sin_t = a->sin_t; k.spw = a->spw;
+  k.cmap = a->cmap; k.strip_map = a->strip_map;
+  k.sk_scratch = a->sk_scratch; k.sk_tickets = a->sk_tickets; k.kv_vblocked = a->kv_vblocked;
+  k.row_b = a->row_b; k.seg_off = a->seg_off;
+  return DIA_OK;
+}
+
 // large-LDS attribute of every small-M instantiation, set once outside any graph capture
 int dia_gemm_init() {
   int rc = 0;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fused<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_smem(64, 128)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fused<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_smem(16, 16)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 4, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 4, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 4)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 4)) != hipSuccess) rc = 1;
@@ -930,16 +1171,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   if (a->ssq_in && a->ssq_ld < ((a->M + 15) / 16) * 16) return dia_fail(DIA_E_ARG, "dia_gemm: ssq_ld smaller than padded rows");
 
   GemmK k;
-  k.A = (const bf16_raw*)a->A; k.a_plane_stride = a->a_plane_stride; k.a_ktiles = a->a_ktiles; k.M = a->M;
-  k.W = (const bf16_raw*)a->W; k.KT = a->KT; k.nstrips = a->nstrips; k.epi = a->epi;
-  k.ssq_in = a->ssq_in; k.ssq_in_n = a->ssq_in_n; k.ssq_ld = a->ssq_ld; k.inv_d = a->inv_d; k.eps = a->eps;
-  k.out = a->out; k.ldo = a->ldo; k.gnext = a->gnext;
-  k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles; k.ssq_out = a->ssq_out;
-  k.kc = a->kc; k.vc = a->vc; k.kv_dtype = a->kv_dtype; k.kv_heads = a->kv_heads; k.kv_cap = a->kv_cap;
-  k.kv_batch_index = a->kv_batch_index; k.cos_t = a->cos_t; k.sin_t = a->sin_t; k.spw = a->spw;
-  k.cmap = a->cmap; k.strip_map = a->strip_map;
-  k.sk_scratch = a->sk_scratch; k.sk_tickets = a->sk_tickets; k.kv_vblocked = a->kv_vblocked;
-  k.row_b = a->row_b; k.seg_off = a->seg_off;
+  fill_gemmk(a, k);
 
   int nw = a->nw;
   if (nw == 0) {
@@ -1008,6 +1240,49 @@ extern "C" int dia_gemm_timed(const dia_gemm_args* a, void* stream, float* ms_ou
     hipError_t he = hipEventSynchronize(e1);
     if (he == hipSuccess) he = hipEventElapsedTime(ms_out, e0, e1);
     if (he != hipSuccess) rc = dia_fail_hip(he, "dia_gemm_timed");
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+
+extern "C" int dia_mlp_fused(const dia_gemm_args* wi, const dia_gemm_args* wo, int32_t* barrier, void* stream) {
+  if (!wi || !wo || !barrier) return dia_fail(DIA_E_ARG, "dia_mlp_fused: null argument");
+  if (wi->M < 1 || wi->M > 2 || wo->M != wi->M) return dia_fail(DIA_E_ARG, "dia_mlp_fused: 1 or 2 rows only");
+  if (wi->epi != DIA_EPI_SWIGLU_EMIT || wo->epi != DIA_EPI_RESID_EMIT || !wi->ssq_in || !wi->P || wo->A != wi->P || !wo->gnext ||
+      !wo->out || !wo->P || !wo->ssq_out || !wo->sk_scratch || !wo->sk_tickets || wi->cmap || wi->strip_map)
+    return dia_fail(DIA_E_ARG, "dia_mlp_fused: wi must be SWIGLU_EMIT into the planes wo reads, wo RESID_EMIT with split-K scratch");
+  if (wi->nstrips * 8 != wo->KT * 32 || wo->KT % 32 != 0 || wi->KT % 16 != 0 || wi->p_ktiles < wo->KT || wo->a_ktiles != wi->p_ktiles ||
+      wo->a_plane_stride != wi->p_plane_stride)
+    return dia_fail(DIA_E_ARG, "dia_mlp_fused: shapes do not chain");
+  const int G = 2 * wo->nstrips;
+  static int n_cu = 0;
+  if (!n_cu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = -1; }
+  if (n_cu < G) return dia_fail(DIA_E_ARG, "dia_mlp_fused: the grid barrier needs every workgroup resident (2 * wo strips <= CUs)");
+  if (wi->nstrips % G != 0 && wi->nstrips < G) return dia_fail(DIA_E_ARG, "dia_mlp_fused: too few wi strips");
+  int rc = dia_kernels_init_once();
+  if (rc) return rc;
+  MlpK q;
+  rc = fill_gemmk(wi, q.wi); if (rc) return rc;
+  rc = fill_gemmk(wo, q.wo); if (rc) return rc;
+  q.bar = barrier;
+  const int kpw1 = wi->KT / 16, kpw2 = wo->KT / 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (kpw1 == 4 && kpw2 == 8) { launch_kernel(k_mlp_fused<4, 8>, dim3(G), dim3(1024), mlp_smem(64, 128), st, q); return dia_check_launch("k_mlp_fused"); }
+  if (kpw1 == 1 && kpw2 == 1) { launch_kernel(k_mlp_fused<1, 1>, dim3(G), dim3(1024), mlp_smem(16, 16), st, q); return dia_check_launch("k_mlp_fused"); }
+  return dia_fail(DIA_E_ARG, "dia_mlp_fused: no instantiation for these K sizes");
+}
+
+extern "C" int dia_mlp_fused_timed(const dia_gemm_args* wi, const dia_gemm_args* wo, int32_t* barrier, void* stream, float* ms_out) {
+  if (!ms_out) return dia_fail(DIA_E_ARG, "dia_mlp_fused_timed: null output");
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return dia_fail(DIA_E_HIP, "hipEventCreate");
+  g_ev_start = e0; g_ev_stop = e1;
+  int rc = dia_mlp_fused(wi, wo, barrier, stream);
+  g_ev_start = g_ev_stop = nullptr;
+  if (rc == DIA_OK) {
+    hipError_t he = hipEventSynchronize(e1);
+    if (he == hipSuccess) he = hipEventElapsedTime(ms_out, e0, e1);
+    if (he != hipSuccess) rc = dia_fail_hip(he, "dia_mlp_fused_timed");
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return rc;

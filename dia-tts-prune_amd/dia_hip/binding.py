@@ -20,7 +20,7 @@ EPI_SCALE_STORE, EPI_RESID_EMIT, EPI_SWIGLU_EMIT, EPI_CROSSKV = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
 
 EXPORTS = (
-    "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_gemm_timed", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep", "dia_enc_attn",
+    "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_gemm_timed", "dia_mlp_fused", "dia_mlp_fused_timed", "dia_engine_mlp_fused", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep", "dia_enc_attn",
     "dia_embed_text", "dia_embed_tokens", "dia_sample", "dia_prefetch", "dia_engine_create", "dia_engine_destroy",
     "dia_engine_decode", "dia_engine_set_prefetch", "dia_engine_step_logits_only", "dia_engine_profile_step", "dia_engine_launches_per_step",
 )
@@ -118,7 +118,7 @@ class EngineDesc(C.Structure):
         ("ssq", C.c_void_p), ("qkv", C.c_void_p), ("qc", C.c_void_p), ("logits", C.c_void_p),
         ("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("text_len", C.c_void_p),
         ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p),
-        ("attn_scratch", C.c_void_p), ("attn_tickets", C.c_void_p),
+        ("attn_scratch", C.c_void_p), ("attn_tickets", C.c_void_p), ("mlp_barrier", C.c_void_p),
         ("sample", SampleArgs),
     ]
 
@@ -154,6 +154,9 @@ def lib() -> C.CDLL:
         raise DiaHipError(f"ABI mismatch: library {L.dia_abi_version()} vs binding {ABI_VERSION}")
     L.dia_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
     L.dia_gemm_timed.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.POINTER(C.c_float)]
+    L.dia_mlp_fused.argtypes = [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.c_void_p, C.c_void_p]
+    L.dia_mlp_fused_timed.argtypes = [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    L.dia_engine_mlp_fused.argtypes = [C.c_void_p]
     L.dia_attn.argtypes = [C.POINTER(AttnArgs), C.c_void_p]
     L.dia_attn_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     L.dia_enc_attn.argtypes = [C.POINTER(EncAttnArgs), C.c_void_p]

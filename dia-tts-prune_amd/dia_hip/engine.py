@@ -238,6 +238,7 @@ class DecodeSession:
         self.attn_tickets = z(max(self.R * d.kv_heads, B * d.cross_query_heads), dt=torch.int32)
         self.sk_scratch = z((self.D // 16) * 4 * 256)
         self.sk_tickets = z(self.D // 16, dt=torch.int32)
+        self.mlp_barrier = z(2, dt=torch.int32)          # dia_mlp_fused: arrivals, error flag
 
         # token buffer + state machine (state.py:178-208; model.py:736-741)
         from .tokens import delayed_prefill
@@ -356,6 +357,7 @@ class DecodeSession:
         ed.cos_t, ed.sin_t, ed.text_len = hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(self.text_len)
         ed.attn_scratch, ed.attn_tickets = hb.ptr(self.attn_scratch), hb.ptr(self.attn_tickets)
         ed.sk_scratch, ed.sk_tickets = hb.ptr(self.sk_scratch), hb.ptr(self.sk_tickets)
+        ed.mlp_barrier = hb.ptr(self.mlp_barrier)
         ed.sample = self._sample_args()
         self._desc = ed
         hb.check(hb.lib().dia_engine_create(C.byref(ed), C.c_void_p(self.stream.cuda_stream), C.byref(self._engine)),
@@ -523,6 +525,44 @@ class DecodeSession:
                 tot += ms.value
         return tot * 1e-3 / (reps * len(args))
 
+    def mlp_fused(self) -> bool:
+        return bool(hb.lib().dia_engine_mlp_fused(self._engine))
+
+    def time_mlp_launches(self, reps: int = 5) -> float:
+        """Average seconds per launch of the fused MLP kernel (wi + wo, batch 1), dispatch-level events, cycling
+        through every layer's matrices with the engine's own arguments (outputs are scratch: x is restored)."""
+        L = hb.lib()
+        st = C.c_void_p(self.stream.cuda_stream)
+        x_keep = self.x.clone()
+        pairs = []
+        for i, DL in enumerate(self.w.dec_layers):
+            a = hb.GemmArgs()
+            a.A, a.a_plane_stride, a.a_ktiles, a.M = hb.ptr(self.planes_x), self.planes_x[0].numel(), self.xkt, self.R
+            a.W, a.KT, a.nstrips, a.epi = hb.ptr(DL["wi"].t), DL["wi"].kt, DL["wi"].ns, hb.EPI_SWIGLU_EMIT
+            a.ssq_in, a.ssq_in_n, a.ssq_ld = hb.ptr(self.ssq), self.D // 16, self.rows_pad
+            a.inv_d, a.eps = 1.0 / self.D, float(self.cfg.model.normalization_layer_epsilon)
+            a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(self.planes_h), self.planes_h[0].numel(), self.hkt
+            b = hb.GemmArgs()
+            b.A, b.a_plane_stride, b.a_ktiles, b.M = hb.ptr(self.planes_h), self.planes_h[0].numel(), self.hkt, self.R
+            b.W, b.KT, b.nstrips, b.epi = hb.ptr(DL["wo"].t), DL["wo"].kt, DL["wo"].ns, hb.EPI_RESID_EMIT
+            b.ssq_ld, b.out, b.ldo = self.rows_pad, hb.ptr(self.x), self.D
+            b.gnext = hb.ptr(self.w.dec_layers[i + 1]["g_sa"] if i + 1 < len(self.w.dec_layers) else self.w.dec_norm)
+            b.P, b.p_plane_stride, b.p_ktiles, b.ssq_out = hb.ptr(self.planes_x), self.planes_x[0].numel(), self.xkt, hb.ptr(self.ssq)
+            b.sk_scratch, b.sk_tickets, b.sk = hb.ptr(self.sk_scratch), hb.ptr(self.sk_tickets), 2
+            pairs.append((a, b))
+        bar = hb.ptr(self.mlp_barrier)
+        for a, b in pairs:
+            hb.check(L.dia_mlp_fused(C.byref(a), C.byref(b), bar, st), "dia_mlp_fused")
+        self.stream.synchronize()
+        ms = C.c_float()
+        tot = 0.0
+        for _ in range(reps):
+            for a, b in pairs:
+                hb.check(L.dia_mlp_fused_timed(C.byref(a), C.byref(b), bar, st, C.byref(ms)), "dia_mlp_fused_timed")
+                tot += ms.value
+        self.x.copy_(x_keep)
+        return tot * 1e-3 / (reps * len(pairs))
+
     def sync(self):
         self.stream.synchronize()
 
@@ -549,6 +589,8 @@ class DecodeSession:
 
     def results(self) -> List[UtteranceResult]:
         self.sync()
+        if int(self.mlp_barrier[1].item()) != 0:
+            raise hb.DiaHipError("fused MLP kernel: a workgroup gave up waiting at the grid barrier; results are invalid")
         tok = self.tokens.cpu().numpy()
         prd = self.pred.cpu().numpy()
         fsm = self.fsm.cpu().numpy()

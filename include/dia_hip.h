@@ -110,6 +110,17 @@ typedef struct {
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
  * kernel's own duration in milliseconds and synchronises on its end */
+/* Fused SwiGLU MLP for 1-2 rows (batch 1): wi (DIA_EPI_SWIGLU_EMIT into planes P) and wo (DIA_EPI_RESID_EMIT reading
+ * those planes, with sk_scratch / sk_tickets for a split-K of 2) in one persistent launch with a grid barrier
+ * between the phases (MlpBlock.forward, layers.py:92-105).  `barrier`: two int32 on the device, zeroed by the
+ * caller once per session; barrier[1] != 0 afterwards means a workgroup gave up waiting (results invalid).
+ * Returns DIA_E_ARG when the shapes do not chain, no instantiation exists or 2 * wo->nstrips exceeds the CU
+ * count (every workgroup must be resident) — callers then issue the two dia_gemm launches instead. */
+int dia_mlp_fused(const dia_gemm_args* wi, const dia_gemm_args* wo, int32_t* barrier, void* stream);
+/* same, bracketed by dispatch-level start/stop events; *ms_out = kernel duration (blocks until it finished) */
+int dia_mlp_fused_timed(const dia_gemm_args* wi, const dia_gemm_args* wo, int32_t* barrier, void* stream, float* ms_out);
+
+
 int dia_gemm_timed(const dia_gemm_args* a, void* stream, float* ms_out);
 
 /* Single-query attention (decode) and the encoder's bidirectional attention on the same kernel.
@@ -293,12 +304,15 @@ typedef struct {
   int32_t* sk_tickets;      /* D/16 int32, zeroed by the caller once */
   float* attn_scratch;      /* max over self/cross of dia_attn_scratch_floats(...) floats */
   int32_t* attn_tickets;    /* max(R*kv_heads, B*cq_heads) int32, zeroed by the caller once */
+  int32_t* mlp_barrier;     /* 2 int32 zeroed by the caller once: dia_mlp_fused's barrier words (NULL = never fuse) */
   dia_sample_args sample;   /* sampler + FSM + embedding parameters */
 } dia_engine_desc;
 
 typedef struct dia_engine dia_engine;
 int dia_engine_create(const dia_engine_desc* d, void* stream, dia_engine** out);
 int dia_engine_destroy(dia_engine* e);
+/* 1 when the engine's decode step runs the MLP as one fused launch (dia_mlp_fused: batch 1, shapes with an instantiation) */
+int dia_engine_mlp_fused(const dia_engine* e);
 /* enqueue `n_steps` decode steps; use_graph != 0 replays a captured hipGraph of one step */
 int dia_engine_decode(dia_engine* e, int n_steps, int use_graph);
 /* before the first graph decode: prefetch the weights of launch i+lookahead into the Infinity Cache

@@ -149,6 +149,78 @@ def test_gemm_swiglu_emit(M, K, F):
     assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,D,F", [(2, 512, 1024), (1, 512, 1024), (2, 2048, 8192)])
+def test_mlp_fused(M, D, F):
+    """dia_mlp_fused: wi (SwiGLU) and wo (residual + planes + ssq) in one persistent launch with a grid barrier,
+    against float64 and against the two separate launches; repeated launches reuse the barrier counter."""
+    d = dev()
+    torch.manual_seed(D + M)
+    x = torch.randn(M, D, device=d)
+    gw = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+    wi = bf16r(torch.randn(D, 2, F, device=d) * 0.05)
+    wo = bf16r(torch.randn(F, D, device=d) * 0.03)
+    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+    x0 = torch.randn(M, D, device=d)
+    Wi, kti, nsi = lay.tile_weight(lay.interleave_gate_up(wi))
+    Wo, kto, nso = lay.tile_weight(wo)
+    A = lay.pack_planes(x * gw)
+    ssq_in = strip_ssq(x, 16)
+    L = hb.lib()
+
+    def args(xres, Ph, Px, ssq_out, skscr, sktk):
+        a = hb.GemmArgs()
+        a.A, a.a_plane_stride, a.a_ktiles, a.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+        a.W, a.KT, a.nstrips, a.epi = hb.ptr(Wi), kti, nsi, hb.EPI_SWIGLU_EMIT
+        a.ssq_in, a.ssq_in_n, a.inv_d, a.eps, a.ssq_ld = hb.ptr(ssq_in), D // 16, 1.0 / D, 1e-5, 16
+        a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(Ph), Ph[0].numel(), F // 32
+        b = hb.GemmArgs()
+        b.A, b.a_plane_stride, b.a_ktiles, b.M = hb.ptr(Ph), Ph[0].numel(), F // 32, M
+        b.W, b.KT, b.nstrips, b.epi = hb.ptr(Wo), kto, nso, hb.EPI_RESID_EMIT
+        b.ssq_ld, b.out, b.ldo, b.gnext = 16, hb.ptr(xres), D, hb.ptr(gn)
+        b.P, b.p_plane_stride, b.p_ktiles, b.ssq_out = hb.ptr(Px), Px[0].numel(), D // 32, hb.ptr(ssq_out)
+        b.sk_scratch, b.sk_tickets, b.sk = hb.ptr(skscr), hb.ptr(sktk), 2
+        return a, b
+
+    def fresh():
+        return (x0.clone(), torch.zeros(3, 1, F // 32, 64, 8, dtype=torch.bfloat16, device=d),
+                torch.zeros(3, 1, D // 32, 64, 8, dtype=torch.bfloat16, device=d), torch.zeros(D // 16, 16, device=d),
+                torch.zeros((D // 16) * 4 * 256, device=d), torch.zeros(D // 16, dtype=torch.int32, device=d))
+
+    bar = torch.zeros(2, dtype=torch.int32, device=d)
+    outs = []
+    for rep in range(3):                                   # the counter keeps counting across launches
+        bufs = fresh()
+        a, b = args(*bufs)
+        hb.check(L.dia_mlp_fused(C.byref(a), C.byref(b), hb.ptr(bar), None), "dia_mlp_fused")
+        torch.cuda.synchronize()
+        outs.append(bufs)
+    assert bar.tolist() == [3 * 2 * nso, 0] and (outs[0][5] == 0).all()
+    xd = x.double()
+    hdn = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
+    f = torch.einsum("mk,kgf->mgf", hdn, wi.double())
+    h_ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
+    xr, Ph, Px, ssq_o = outs[0][:4]
+    h_got = lay.unpack_planes(Ph, M, F)
+    assert (h_got.double() - h_ref).abs().max().item() <= 2e-5 * max(1.0, h_ref.abs().max().item())
+    ref = x0.double() + h_got.double() @ wo.double()       # wo consumes the fp32 h the planes carry
+    assert (xr.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert torch.equal(lay.unpack_planes(Px, M, D), xr * gn)
+    want = (xr.double() ** 2).reshape(M, D // 16, 16).sum(-1).T
+    assert (ssq_o[:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
+    for o in outs[1:]:
+        assert torch.equal(o[0], xr) and torch.equal(o[2], Px)            # bit-reproducible
+    # the two separate launches agree to fp32 rounding (their waves split K differently)
+    bufs = fresh()
+    a, b = args(*bufs)
+    hb.check(L.dia_gemm(C.byref(a), None), "wi"); hb.check(L.dia_gemm(C.byref(b), None), "wo")
+    torch.cuda.synchronize()
+    assert (lay.unpack_planes(bufs[1], M, F) - h_got).abs().max().item() <= 1e-5 * max(1.0, h_ref.abs().max().item())
+    assert (bufs[0] - xr).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    # shapes that do not chain are refused, nothing is launched
+    b.KT = kto // 2
+    assert L.dia_mlp_fused(C.byref(a), C.byref(b), hb.ptr(bar), None) == -1
+
+
 @pytest.mark.parametrize("kvd", ["f32", "bf16"])
 def test_gemm_crosskv(kvd):
     d = dev()
