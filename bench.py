@@ -139,10 +139,9 @@ def main():
     prefill_gpu_s = ev0.elapsed_time(ev1) * 1e-3
     e_, d_ = cfg.model.encoder, cfg.model.decoder
     rows_ = sum(sess.lens)
-    enc_params = e_.n_layer * (e_.n_embd * 3 * e_.n_head * 128 + e_.n_head * 128 * e_.n_embd + 3 * e_.n_embd * e_.n_hidden)
-    ckv_params = d_.n_layer * e_.n_embd * 2 * d_.cross_query_heads * 128
+    prefill_params = w.prefill_weight_bytes() / 2.0          # encoder + cross-K/V matrices as loaded (compacted if pruned)
     attn_flops = e_.n_layer * e_.n_head * 4 * 128 * sum(l * l for l in sess.lens)
-    prefill_flops = 2.0 * rows_ * (enc_params + ckv_params) + attn_flops
+    prefill_flops = 2.0 * rows_ * prefill_params + attn_flops
     MFMA_PEAK_TFLOPS = 2500.0                      # dense bf16, MI355X_MICROARCH.md
     prefill = {"text_bytes": rows_, "gpu_s": round(prefill_gpu_s, 5), "host_s_first_call": round(prefill_s, 4),
                "algorithmic_tflop": round(prefill_flops / 1e12, 4),

@@ -1222,7 +1222,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
     const int blocks = ((mtiles + GT_MT - 1) / GT_MT) * ((a->nstrips + 15) / 16);
     int min_blocks = 48;
     if (const char* e = getenv("DIA_DBG_TILE_MIN")) min_blocks = atoi(e);
-    if (mtiles >= 3 && a->KT % 8 == 0 && !a->cmap && blocks >= min_blocks) return launch_tile(k, st);
+    if (mtiles >= 3 && a->KT % 8 == 0 && blocks >= min_blocks) return launch_tile(k, st);
   }
   if (mtiles == 1) return launch_nw<1>(k, nw, 1, st);
   if (mtiles == 2) return launch_nw<2>(k, nw, 1, st);

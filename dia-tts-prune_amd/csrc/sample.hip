@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_embed_tokens(EmbedK e) {
 
 __global__ __launch_bounds__(256) void k_embed_text(const int* ids, int L, const float* table, int D, const float* g,
                                                     float* x, bf16_raw* P, long p_plane_stride, int p_ktiles,
-                                                    float* ssq, int ssq_ld) {
+                                                    float* ssq, int ssq_ld, const int* cmap) {
   const int m = blockIdx.x;
   const float* row = table + (long)ids[m] * D;
   for (int d0 = threadIdx.x * 8; d0 < D; d0 += 256 * 8) {
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void k_embed_text(const int* ids, int L, const
     float* xo = x + (long)m * D + d0;
     *reinterpret_cast<float4*>(xo) = a;
     *reinterpret_cast<float4*>(xo + 4) = bq;
-    emit_planes8(P, p_plane_stride, p_ktiles, m, d0, vg);
+    if (cmap) emit_planes8_mapped(P, p_plane_stride, p_ktiles, m, d0, vg, cmap);
+    else emit_planes8(P, p_plane_stride, p_ktiles, m, d0, vg);
     if (((d0 >> 3) & 1) == 0) ssq[(long)(d0 >> 4) * ssq_ld + m] = ss + other;
   }
 }
@@ -382,11 +383,12 @@ extern "C" int dia_embed_tokens(const dia_embed_args* a, void* stream) {
 }
 
 extern "C" int dia_embed_text(const int32_t* ids, int L, const float* table, int D, const float* g, float* x,
-                              void* P, int64_t p_plane_stride, int p_ktiles, float* ssq, int ssq_ld, void* stream) {
-  if (!ids || !table || !x || !P || !ssq || L <= 0 || D % 16 != 0 || p_ktiles * 32 < D || p_plane_stride % 8 != 0)
+                              void* P, int64_t p_plane_stride, int p_ktiles, float* ssq, int ssq_ld, const int32_t* cmap,
+                              void* stream) {
+  if (!ids || !table || !x || !P || !ssq || L <= 0 || D % 16 != 0 || (!cmap && p_ktiles * 32 < D) || p_plane_stride % 8 != 0)
     return dia_fail(DIA_E_ARG, "dia_embed_text: bad argument");
   hipLaunchKernelGGL(k_embed_text, dim3(L), dim3(256), 0, (hipStream_t)stream, ids, L, table, D, g, x,
-                     (bf16_raw*)P, (long)p_plane_stride, p_ktiles, ssq, ssq_ld);
+                     (bf16_raw*)P, (long)p_plane_stride, p_ktiles, ssq, ssq_ld, cmap);
   return dia_check_launch("k_embed_text");
 }
 

@@ -14,7 +14,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIA_HIP_LIB") or os.path.join(_HERE, "libdia_hip.so")   # override: experiments only
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 KV_F32, KV_BF16 = 0, 1
 EPI_SCALE_STORE, EPI_RESID_EMIT, EPI_SWIGLU_EMIT, EPI_CROSSKV = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
@@ -163,7 +163,7 @@ def lib() -> C.CDLL:
     L.dia_enc_kv_prep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dia_embed_text.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+                                 C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.dia_embed_tokens.argtypes = [C.POINTER(EmbedArgs), C.c_void_p]
     L.dia_sample.argtypes = [C.POINTER(SampleArgs), C.c_void_p]
     L.dia_prefetch.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]

@@ -12,6 +12,10 @@ recovered from the zeros.  Compaction then
   whose every query head is gone) unnecessary, hidden units zeroed in ``wo`` make the matching gate/up
   columns of ``wi_fused`` unnecessary (N-compaction, ``strip_map`` / ``head_map``).
 
+The encoder (prefill only) is compacted the same way (``plan_encoder_layer``: a dead head drops its q, k and v
+columns); the cross K/V projections keep their full K because every decoder layer has its own keep set over the
+one encoder output.
+
 A zero row contributes exactly 0.0 to an fp32 dot product, so results equal the zero-streaming path up
 to summation order.  q, k and v share one activation plane set, so their K-compaction uses the union
 of the three keep sets (rows zero in only one of them are stored as zeros).
@@ -83,6 +87,26 @@ def plan_decoder_layer(sd: Dict[str, torch.Tensor], prefix: str, q_heads: int, k
     keep_ckv = rows("cross_attention.k_proj.weight") | rows("cross_attention.v_proj.weight")
     return LayerPlan(pad_keep(keep_qkv), pad_keep(rows("cross_attention.q_proj.weight")), pad_keep(rows("mlp.wi_fused.weight")),
                      live_q, live_kv, live_c, rows("mlp.wo.weight"), keep_ckv)
+
+
+@dataclass
+class EncLayerPlan:
+    keep_qkv: torch.Tensor            # bool [E]  union of q/k/v input rows (padded)
+    keep_wi: torch.Tensor             # bool [E]
+    live_heads: torch.Tensor          # bool [heads]   (from o_proj: a dead head drops its q, k AND v columns — MHA)
+    live_hidden: torch.Tensor         # bool [F]       (from wo)
+
+
+def plan_encoder_layer(sd: Dict[str, torch.Tensor], prefix: str, heads: int) -> EncLayerPlan:
+    g = lambda n: sd[prefix + n]
+    rows = lambda n: nonzero_rows(g(n).reshape(g(n).shape[0], -1))
+    keep_qkv = rows("self_attention.q_proj.weight") | rows("self_attention.k_proj.weight") | rows("self_attention.v_proj.weight")
+    live = nonzero_rows(g("self_attention.o_proj.weight").reshape(heads, -1))
+    return EncLayerPlan(pad_keep(keep_qkv), pad_keep(rows("mlp.wi_fused.weight")), live, rows("mlp.wo.weight"))
+
+
+def enc_is_pruned(plan: EncLayerPlan) -> bool:
+    return not bool(plan.keep_qkv.all() and plan.keep_wi.all() and plan.live_heads.all() and plan.live_hidden.all())
 
 
 def is_pruned(plan: LayerPlan) -> bool:

@@ -67,15 +67,41 @@ class DeviceWeights:
         perm = lay.rope_pair_perm(HEAD_DIM).to(device)
         self.enc_emb = dev("encoder.embedding.weight").contiguous()
         self.enc_layers = []
+        i32e = lambda t: t.to(device=device, dtype=torch.int32).contiguous()
+        E, EH = e.n_embd, e.n_head
+        eplans = []
+        for i in range(e.n_layer):
+            pl = cpt.plan_encoder_layer({k: v for k, v in sd.items() if k.startswith(f"encoder.layers.{i}.")},
+                                        f"encoder.layers.{i}.", EH)
+            eplans.append(pl if (compact != "off" and cpt.enc_is_pruned(pl)) else None)
         for i in range(e.n_layer):
             p = f"encoder.layers.{i}."
-            E = e.n_embd
-            qkv = torch.cat([dev(p + f"self_attention.{n}_proj.weight").reshape(E, -1) for n in "qkv"], dim=1)
-            self.enc_layers.append(dict(
-                g_sa=dev(p + "pre_sa_norm.weight").contiguous(), g_mlp=dev(p + "post_sa_norm.weight").contiguous(),
-                qkv=tile(qkv), o=tile(dev(p + "self_attention.o_proj.weight").reshape(-1, E)),
-                wi=tile(lay.interleave_gate_up(dev(p + "mlp.wi_fused.weight"))), wo=tile(dev(p + "mlp.wo.weight")),
-            ))
+            P = eplans[i]
+            wq, wk, wv = (dev(p + f"self_attention.{n}_proj.weight").reshape(E, -1) for n in "qkv")
+            o = dev(p + "self_attention.o_proj.weight").reshape(-1, E)
+            wi3 = dev(p + "mlp.wi_fused.weight")
+            wo = dev(p + "mlp.wo.weight")
+            EL = dict(g_sa=dev(p + "pre_sa_norm.weight").contiguous(), g_mlp=dev(p + "post_sa_norm.weight").contiguous(),
+                      heads=EH, cmap_mlp=None, cmap_next=None)
+            nxt = eplans[i + 1] if i + 1 < e.n_layer else None
+            if nxt is not None:
+                EL["cmap_next"] = i32e(cpt._cmap(nxt.keep_qkv))
+            if P is not None:
+                hc = P.live_heads.to(device).repeat_interleave(HEAD_DIM)            # live head columns
+                kq = P.keep_qkv.to(device)
+                wq, wk, wv = wq[kq][:, hc], wk[kq][:, hc], wv[kq][:, hc]
+                o = o[hc]
+                hid = cpt.pad_hidden_keep(P.live_hidden).to(device)
+                wi3 = torch.stack([cpt.take_cols_idx(wi3[:, 0, :], hid), cpt.take_cols_idx(wi3[:, 1, :], hid)], dim=1)
+                wi3 = wi3[P.keep_wi.to(device)]
+                wo_c = wo[hid.clamp(min=0)].clone()
+                wo_c[hid < 0] = 0
+                wo = wo_c
+                EL.update(heads=int(P.live_heads.sum()), cmap_mlp=i32e(cpt._cmap(P.keep_wi)))
+            EL.update(qkv=tile(torch.cat([wq, wk, wv], dim=1)), o=tile(o), wi=tile(lay.interleave_gate_up(wi3)), wo=tile(wo))
+            self.enc_layers.append(EL)
+        self.enc_cmap_first = i32e(cpt._cmap(eplans[0].keep_qkv)) if eplans and eplans[0] is not None else None
+        self.enc_compacted = any(pl is not None for pl in eplans)
         self.enc_norm = dev("encoder.norm.weight").contiguous()
         self.dec_emb = torch.stack([dev(f"decoder.embeddings.{c}.weight") for c in range(cfg.data.channels)]).contiguous()
         self.dec_layers = []
@@ -88,7 +114,7 @@ class DeviceWeights:
             plans.append(pl if (compact != "off" and cpt.is_pruned(pl)) else None)
         keep_logits = cpt.pad_keep(cpt.nonzero_rows(sd["decoder.logits_dense.weight"].reshape(D, -1)))
         logits_pruned = compact != "off" and not bool(keep_logits.all())
-        self.compacted = any(p is not None for p in plans) or logits_pruned
+        self.compacted = any(p is not None for p in plans) or logits_pruned or self.enc_compacted
         i32 = lambda t: t.to(device=device, dtype=torch.int32).contiguous()
         ones_d = torch.ones(D, dtype=torch.bool)
 
@@ -157,6 +183,11 @@ class DeviceWeights:
         from .weights import param_shapes
         sd = {k: torch.zeros(shp, dtype=torch.float32, device=device) for k, shp in param_shapes(cfg).items()}
         return cls(cfg, sd, device, compact="off")
+
+    def prefill_weight_bytes(self) -> int:
+        """bf16 bytes the prefill streams once per batch: the encoder and the cross K/V projections"""
+        n = sum(L[k].nbytes for L in self.enc_layers for k in ("qkv", "o", "wi", "wo"))
+        return n + sum(L["ckv"].nbytes for L in self.dec_layers)
 
     def decode_weight_bytes(self) -> int:
         """bf16 bytes one decode step streams (SURVEY.md §8d 'W'): every decoder matrix except the
@@ -399,15 +430,18 @@ class DecodeSession:
             if tot > 0:
                 Mp, mt = tot, tot // 16
                 Lmax = _ceil(max(self.lens), 16)
-                ekt, akt, hkt = E // 32, e.n_head * HEAD_DIM // 32, Fe // 32
+                Hmax = max(EL["heads"] for EL in w.enc_layers)
+                ekt = E // 32
+                akt = max(1, Hmax * HEAD_DIM // 32)
+                hkt = max(EL["wo"].kt for EL in w.enc_layers)                 # (compacted) hidden width in k-tiles
                 z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)
                 x = z(Mp, E)
                 px, pa, ph = (z(3, mt, kt_, 64, 8, dt=torch.bfloat16) for kt_ in (ekt, akt, hkt))
                 ssq = z(E // 16, Mp)
-                nq = 3 * e.n_head * HEAD_DIM
-                qkv = z(Mp, nq)
-                kp = z(3, e.n_head, Mp, HEAD_DIM, dt=torch.bfloat16)           # K / V planes of the attention (scratch)
-                vp = z(3, e.n_head, Mp, HEAD_DIM, dt=torch.bfloat16)
+                nq_max = 3 * Hmax * HEAD_DIM
+                qkv = z(Mp, nq_max)
+                kp = z(3, Hmax, Mp, HEAD_DIM, dt=torch.bfloat16)           # K / V planes of the attention (scratch)
+                vp = z(3, Hmax, Mp, HEAD_DIM, dt=torch.bfloat16)
                 rb = np.full((Mp,), -1, dtype=np.int32)
                 for b, Lb in enumerate(self.lens):
                     rb[offs[b]: offs[b] + Lb] = b
@@ -426,10 +460,10 @@ class DecodeSession:
                     ids = torch.from_numpy(self.text_ids[b]).to(dev)
                     hb.check(L.dia_embed_text(hb.ptr(ids), self.lens[b], hb.ptr(w.enc_emb), E, hb.ptr(w.enc_layers[0]["g_sa"]),
                                               rows(x, b, E), planes_at(px, b, ekt), px[0].numel(), ekt,
-                                              ssq.data_ptr() + offs[b] * 4, Mp, st), "dia_embed_text")
+                                              ssq.data_ptr() + offs[b] * 4, Mp, hb.ptr(w.enc_cmap_first), st), "dia_embed_text")
 
                 def gemm(A, a_kt, W: TiledW, epi, *, M=Mp, a_ptr=None, ssq_ptr=None, ssq_in=False, out=None, ldo=0, gnext=None,
-                         P=None, p_kt=0, ssq_out=False, kv=None, strip_map=None, row_map=False):
+                         P=None, p_kt=0, ssq_out=False, kv=None, strip_map=None, row_map=False, cmap=None):
                     g = hb.GemmArgs()
                     g.A, g.a_plane_stride, g.a_ktiles, g.M = (a_ptr if a_ptr is not None else hb.ptr(A)), A[0].numel(), a_kt, M
                     g.W, g.KT, g.nstrips, g.epi = hb.ptr(W.t), W.kt, W.ns, epi
@@ -444,6 +478,7 @@ class DecodeSession:
                     if ssq_out:
                         g.ssq_out = sp
                     g.strip_map = hb.ptr(strip_map)
+                    g.cmap = hb.ptr(cmap)
                     g.kv_vblocked = self.v_blocked if kv is not None else 0
                     if kv is not None:
                         g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = kv
@@ -453,18 +488,25 @@ class DecodeSession:
                     hb.check(L.dia_gemm(C.byref(g), st), "dia_gemm")
 
                 for i, EL in enumerate(w.enc_layers):
-                    gemm(px, ekt, EL["qkv"], hb.EPI_SCALE_STORE, ssq_in=True, out=qkv, ldo=nq)
-                    ea_ = hb.EncAttnArgs()
-                    ea_.qkv, ea_.ldq, ea_.q_off, ea_.k_off, ea_.v_off = hb.ptr(qkv), nq, 0, e.n_head * HEAD_DIM, 2 * e.n_head * HEAD_DIM
-                    ea_.heads, ea_.rows = e.n_head, Mp
-                    ea_.row_b, ea_.seg_off, ea_.seg_len = hb.ptr(row_b), hb.ptr(seg_off), hb.ptr(seg_len)
-                    ea_.cos_t, ea_.sin_t, ea_.kp, ea_.vp = hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(kp), hb.ptr(vp)
-                    ea_.P, ea_.p_plane_stride, ea_.p_ktiles = hb.ptr(pa), pa[0].numel(), akt
-                    hb.check(L.dia_enc_attn(C.byref(ea_), st), "dia_enc_attn")
-                    gemm(pa, akt, EL["o"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=EL["g_mlp"], P=px, p_kt=ekt, ssq_out=True)
+                    Hl = EL["heads"]                 # live heads of this layer (all of them unless the checkpoint was pruned)
+                    nq = 3 * Hl * HEAD_DIM
+                    if Hl > 0:
+                        gemm(px, ekt, EL["qkv"], hb.EPI_SCALE_STORE, ssq_in=True, out=qkv, ldo=nq)
+                        ea_ = hb.EncAttnArgs()
+                        ea_.qkv, ea_.ldq, ea_.q_off, ea_.k_off, ea_.v_off = hb.ptr(qkv), nq, 0, Hl * HEAD_DIM, 2 * Hl * HEAD_DIM
+                        ea_.heads, ea_.rows = Hl, Mp
+                        ea_.row_b, ea_.seg_off, ea_.seg_len = hb.ptr(row_b), hb.ptr(seg_off), hb.ptr(seg_len)
+                        ea_.cos_t, ea_.sin_t, ea_.kp, ea_.vp = hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(kp), hb.ptr(vp)
+                        ea_.P, ea_.p_plane_stride, ea_.p_ktiles = hb.ptr(pa), pa[0].numel(), akt
+                        hb.check(L.dia_enc_attn(C.byref(ea_), st), "dia_enc_attn")
+                        gemm(pa, akt, EL["o"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=EL["g_mlp"], P=px, p_kt=ekt, ssq_out=True,
+                             cmap=EL["cmap_mlp"])
+                    else:
+                        raise hb.DiaHipError("encoder layer with every attention head pruned is not supported")
                     gemm(px, ekt, EL["wi"], hb.EPI_SWIGLU_EMIT, ssq_in=True, P=ph, p_kt=hkt)
                     gnext = w.enc_layers[i + 1]["g_sa"] if i + 1 < len(w.enc_layers) else w.enc_norm
-                    gemm(ph, hkt, EL["wo"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=gnext, P=px, p_kt=ekt, ssq_out=True)
+                    gemm(ph, hkt, EL["wo"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=gnext, P=px, p_kt=ekt, ssq_out=True,
+                         cmap=EL["cmap_next"])
                 # px now holds planes(x * encoder.norm.weight); ssq the row sums of squares of x
                 for i, DL in enumerate(w.dec_layers):
                     gemm(px, ekt, DL["ckv"], hb.EPI_CROSSKV, ssq_in=True,

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DIA_ABI_VERSION 1
+#define DIA_ABI_VERSION 2
 
 #define DIA_OK 0
 #define DIA_E_ARG (-1)     /* bad argument / unsupported shape */
@@ -195,9 +195,10 @@ int dia_enc_attn(const dia_enc_attn_args* a, void* stream);
 int dia_enc_kv_prep(const float* qkv, int ldq, int k_off, int v_off, int heads, int L, int cap,
                     const float* cos_t, const float* sin_t, float* kc, float* vc, void* stream);
 
-/* x[m][:] = table[ids[m]][:] for the text encoder (layers.py:452), plus planes(x*g) and strip ssq. */
+/* x[m][:] = table[ids[m]][:] for the text encoder (layers.py:452), plus planes(x*g) and strip ssq.
+ * cmap: as dia_gemm_args.cmap (first encoder layer's q/k/v input order of a compacted checkpoint) or NULL. */
 int dia_embed_text(const int32_t* ids, int L, const float* table, int D, const float* g, float* x,
-                   void* P, int64_t p_plane_stride, int p_ktiles, float* ssq, int ssq_ld, void* stream);
+                   void* P, int64_t p_plane_stride, int p_ktiles, float* ssq, int ssq_ld, const int32_t* cmap, void* stream);
 
 /* Decoder input embedding: x[2b..2b+1][:] = sum_c emb_c[tokens[b][cur[b]-1][c]] (layers.py:691-696). */
 typedef struct {

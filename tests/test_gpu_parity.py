@@ -248,6 +248,7 @@ def test_structured_pruned_checkpoint_is_compacted_and_matches_reference(mid, go
     ratio = wc.decode_weight_bytes() / wz.decode_weight_bytes()
     print(f"pruned mid: decode weight bytes {wc.decode_weight_bytes()} vs {wz.decode_weight_bytes()} (x{ratio:.3f})")
     assert ratio < 0.45                                     # 50 % rows, plus dead heads / hidden units propagated
+    assert wc.enc_compacted and wc.prefill_weight_bytes() < 0.6 * wz.prefill_weight_bytes()   # the encoder shrinks too
     mt = int(g["max_tokens"])
     text = TEXTS[0]
     for w in (wc, wz):
