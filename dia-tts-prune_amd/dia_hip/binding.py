@@ -20,7 +20,7 @@ EPI_SCALE_STORE, EPI_RESID_EMIT, EPI_SWIGLU_EMIT, EPI_CROSSKV = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
 
 EXPORTS = (
-    "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_gemm_timed", "dia_mlp_fused", "dia_mlp_fused_timed", "dia_engine_mlp_fused", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep", "dia_enc_attn",
+    "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_gemm_timed", "dia_mlp_fused", "dia_mlp_fused_timed", "dia_engine_mlp_fused", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep", "dia_enc_attn", "dia_dec_prefill_embed", "dia_dec_prefill_kv", "dia_dec_prefill_attn",
     "dia_embed_text", "dia_embed_tokens", "dia_sample", "dia_prefetch", "dia_engine_create", "dia_engine_destroy",
     "dia_engine_decode", "dia_engine_set_prefetch", "dia_engine_step_logits_only", "dia_engine_profile_step", "dia_engine_launches_per_step",
 )
@@ -66,6 +66,20 @@ class EncAttnArgs(C.Structure):
         ("row_b", C.c_void_p), ("seg_off", C.c_void_p), ("seg_len", C.c_void_p), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("kp", C.c_void_p), ("vp", C.c_void_p), ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32),
         ("_pad0", C.c_int32),
+    ]
+
+
+class DecPrefillArgs(C.Structure):
+    _fields_ = [
+        ("row_seg", C.c_void_p), ("seg_off", C.c_void_p), ("seg_len", C.c_void_p), ("seg_row", C.c_void_p),
+        ("rows", C.c_int32), ("_pad0", C.c_int32),
+        ("tokens", C.c_void_p), ("T", C.c_int32), ("C", C.c_int32), ("V", C.c_int32), ("D", C.c_int32),
+        ("emb", C.c_void_p), ("g", C.c_void_p), ("x", C.c_void_p),
+        ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("ssq_ld", C.c_int32),
+        ("ssq", C.c_void_p),
+        ("q", C.c_void_p), ("ldq", C.c_int32), ("q_off", C.c_int32), ("k_off", C.c_int32), ("v_off", C.c_int32),
+        ("q_heads", C.c_int32), ("kv_heads", C.c_int32), ("kv_cap", C.c_int32), ("causal", C.c_int32),
+        ("kc", C.c_void_p), ("vc", C.c_void_p), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("text_len", C.c_void_p),
     ]
 
 
@@ -160,6 +174,8 @@ def lib() -> C.CDLL:
     L.dia_attn.argtypes = [C.POINTER(AttnArgs), C.c_void_p]
     L.dia_attn_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     L.dia_enc_attn.argtypes = [C.POINTER(EncAttnArgs), C.c_void_p]
+    for fn in (L.dia_dec_prefill_embed, L.dia_dec_prefill_kv, L.dia_dec_prefill_attn):
+        fn.argtypes = [C.POINTER(DecPrefillArgs), C.c_void_p]
     L.dia_enc_kv_prep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dia_embed_text.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

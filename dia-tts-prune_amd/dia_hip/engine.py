@@ -517,9 +517,101 @@ class DecodeSession:
                         Lb, o = self.lens[b], offs[b]
                         inv = torch.rsqrt(ssq[:, o: o + Lb].sum(dim=0) / E + eps)
                         self.enc_out[b] = (x[o: o + Lb] * inv[:, None] * w.enc_norm[None, :]).clone()
+            if self._prompt_prefill_batched():
+                self._prompt_prefill(st)
             ea = self._embed_args()
             hb.check(L.dia_embed_tokens(C.byref(ea), st), "dia_embed_tokens")
         self.prefilled = True
+
+    # ------------------------------------------------------------------ audio-prompt prefill, batched
+    def _prompt_prefill_batched(self) -> bool:
+        """The batched MFMA prefill of the prompt rows needs bf16 caches with the blocked V layout and an
+        uncompacted decoder; everything else replays the prompt rows through the decode step (first_step)."""
+        import os as _os
+        return (any(f > 2 for f in self.first_steps) and self.v_blocked == 1 and not self.w.compacted and not self.teacher
+                and _os.environ.get("DIA_PROMPT_REPLAY") != "1")
+
+    def _prompt_prefill(self, st):
+        """Decoder.forward in prefill mode (layers.py:722-766) for the audio prompts of all utterances at once, with
+        the replay's semantics (token row r -> slot r, position r + 1): packed rows = both CFG rows of every
+        prompted utterance; dense layers on the MFMA-tiled GEMM, K/V append / causal self-attention / cross
+        attention over the caches by the dia_dec_prefill_* kernels.  Afterwards cur[b] = first_step[b]."""
+        L = hb.lib()
+        cfg, w, dev = self.cfg, self.w, self.dev
+        d = cfg.model.decoder
+        D, F = self.D, self.F
+        QH, KVH, CH = d.gqa_query_heads, d.kv_heads, d.cross_query_heads
+        eps = float(cfg.model.normalization_layer_epsilon)
+        segs = []                                   # (cache row 2b+c, prompt rows)
+        for b, fs in enumerate(self.first_steps):
+            if fs > 2:                              # rows 0..fs-2 are prefilled; fs == 2 (one frame) is left to the replay path
+                segs += [(2 * b, fs - 1), (2 * b + 1, fs - 1)]
+        offs, tot = [], 0
+        for _, n in segs:
+            offs.append(tot)
+            tot += _ceil(n, 32)
+        Mp, mt = tot, tot // 16
+        rs = np.full((Mp,), -1, dtype=np.int32)
+        for i, (_, n) in enumerate(segs):
+            rs[offs[i]: offs[i] + n] = i
+        i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)
+        row_seg = torch.from_numpy(rs).to(dev)
+        seg_off, seg_len, seg_row = i32(offs), i32([n for _, n in segs]), i32([r for r, _ in segs])
+        z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)
+        xkt, akt, hkt = D // 32, max(QH, CH) * HEAD_DIM // 32, F // 32
+        x = z(Mp, D)
+        px, pa, ph = (z(3, mt, kt_, 64, 8, dt=torch.bfloat16) for kt_ in (xkt, akt, hkt))
+        ssq = z(D // 16, Mp)
+        qkv, qc = z(Mp, self.nqkv), z(Mp, CH * HEAD_DIM)
+
+        def pargs():
+            a = hb.DecPrefillArgs()
+            a.row_seg, a.seg_off, a.seg_len, a.seg_row, a.rows = hb.ptr(row_seg), hb.ptr(seg_off), hb.ptr(seg_len), hb.ptr(seg_row), Mp
+            a.cos_t, a.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
+            return a
+
+        def gemm(A, a_kt, W: TiledW, epi, *, ssq_in=False, out=None, ldo=0, gnext=None, P=None, p_kt=0, ssq_out=False):
+            g = hb.GemmArgs()
+            g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), a_kt, Mp
+            g.W, g.KT, g.nstrips, g.epi = hb.ptr(W.t), W.kt, W.ns, epi
+            if ssq_in:
+                g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq), D // 16, 1.0 / D, eps
+            g.ssq_ld = Mp
+            g.out, g.ldo, g.gnext = hb.ptr(out), ldo, hb.ptr(gnext)
+            if P is not None:
+                g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), p_kt
+            if ssq_out:
+                g.ssq_out = hb.ptr(ssq)
+            hb.check(L.dia_gemm(C.byref(g), st), "dia_gemm")
+
+        a = pargs()
+        a.tokens, a.T, a.C, a.V, a.D = hb.ptr(self.tokens), self.T, self.C, self.V, D
+        a.emb, a.g, a.x = hb.ptr(w.dec_emb), hb.ptr(w.dec_layers[0]["g_sa"]), hb.ptr(x)
+        a.P, a.p_plane_stride, a.p_ktiles, a.ssq, a.ssq_ld = hb.ptr(px), px[0].numel(), xkt, hb.ptr(ssq), Mp
+        hb.check(L.dia_dec_prefill_embed(C.byref(a), st), "dia_dec_prefill_embed")
+        for i, DL in enumerate(w.dec_layers):
+            gemm(px, xkt, DL["qkv"], hb.EPI_SCALE_STORE, ssq_in=True, out=qkv, ldo=self.nqkv)
+            a = pargs()
+            a.q, a.ldq, a.q_off, a.k_off, a.v_off = hb.ptr(qkv), self.nqkv, 0, QH * HEAD_DIM, (QH + KVH) * HEAD_DIM
+            a.q_heads, a.kv_heads, a.kv_cap, a.causal = QH, KVH, self.T, 1
+            a.kc, a.vc = hb.ptr(self.k_self[i]), hb.ptr(self.v_self[i])
+            a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(pa), pa[0].numel(), akt
+            hb.check(L.dia_dec_prefill_kv(C.byref(a), st), "dia_dec_prefill_kv")
+            hb.check(L.dia_dec_prefill_attn(C.byref(a), st), "dia_dec_prefill_attn(self)")
+            gemm(pa, akt, DL["o"], hb.EPI_RESID_EMIT, out=x, ldo=D, gnext=DL["g_ca"], P=px, p_kt=xkt, ssq_out=True)
+            gemm(px, xkt, DL["cq"], hb.EPI_SCALE_STORE, ssq_in=True, out=qc, ldo=CH * HEAD_DIM)
+            a = pargs()
+            a.q, a.ldq, a.q_off = hb.ptr(qc), CH * HEAD_DIM, 0
+            a.q_heads, a.kv_heads, a.kv_cap, a.causal = CH, CH, self.S, 0
+            a.kc, a.vc, a.text_len = hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i]), hb.ptr(self.text_len)
+            a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(pa), pa[0].numel(), akt
+            hb.check(L.dia_dec_prefill_attn(C.byref(a), st), "dia_dec_prefill_attn(cross)")
+            gemm(pa, akt, DL["co"], hb.EPI_RESID_EMIT, out=x, ldo=D, gnext=DL["g_mlp"], P=px, p_kt=xkt, ssq_out=True)
+            gemm(px, xkt, DL["wi"], hb.EPI_SWIGLU_EMIT, ssq_in=True, P=ph, p_kt=hkt)
+            gnext = w.dec_layers[i + 1]["g_sa"] if i + 1 < len(w.dec_layers) else w.dec_norm
+            gemm(ph, hkt, DL["wo"], hb.EPI_RESID_EMIT, out=x, ldo=D, gnext=gnext, P=px, p_kt=xkt, ssq_out=True)
+        cur = [fs if fs > 2 else 1 for fs in self.first_steps]
+        self.cur.copy_(torch.tensor(cur, dtype=torch.int32))
 
     # ------------------------------------------------------------------ decode
     def decode(self, n_steps: int, use_graph: bool = True):

@@ -190,6 +190,37 @@ typedef struct {
 } dia_enc_attn_args;
 int dia_enc_attn(const dia_enc_attn_args* a, void* stream);
 
+/* Decoder prefill over an audio prompt, batched (Decoder.forward in prefill mode, layers.py:722-766, with the
+ * replay semantics of DESIGN.md §8: token row r -> cache slot r at RoPE position r + 1).  All prompt rows of all
+ * utterances, both CFG rows, are packed: segment s = (utterance b, CFG row c) owns packed rows
+ * [seg_off[s], seg_off[s] + seg_len[s]), seg_off a multiple of 32; row_seg[m] = segment of packed row m or -1;
+ * seg_row[s] = 2b + c (the self-cache row; b = seg_row >> 1 indexes tokens, cross caches and text_len).
+ * bf16 caches with blocked V only.  The dense layers between these three calls are dia_gemm over the packed rows. */
+typedef struct {
+  const int32_t* row_seg; const int32_t* seg_off; const int32_t* seg_len; const int32_t* seg_row;
+  int32_t rows;             /* packed rows, multiple of 32 */
+  int32_t _pad0;
+  /* dia_dec_prefill_embed: x[m] = sum_c emb[c][tokens[b][r][c]], planes(x * g), strip ssq */
+  const int32_t* tokens;    /* [B][T][C] */
+  int32_t T, C, V, D;
+  const float* emb;         /* [C][V][D] */
+  const float* g;           /* first layer's pre-SA norm weight */
+  float* x;                 /* [rows][D] */
+  void* P; int64_t p_plane_stride; int32_t p_ktiles; int32_t ssq_ld;   /* embed: x planes; attn: output planes */
+  float* ssq;               /* [D/16][ssq_ld] */
+  /* dia_dec_prefill_kv (self K/V append of every packed row) and dia_dec_prefill_attn */
+  const float* q;           /* fp32 [rows][ldq]: q head h at q_off + h*128 (kv: k at k_off, v at v_off) */
+  int32_t ldq, q_off, k_off, v_off;
+  int32_t q_heads, kv_heads, kv_cap;
+  int32_t causal;           /* attn: 1 = self (keys 0..r of the segment's cache row), 0 = cross (text keys of the cond segment; uncond -> 0) */
+  void* kc; void* vc;       /* bf16 caches [cache row][kv_heads][kv_cap][128], V blocked [.. kv_cap/32][128][32] */
+  const float* cos_t; const float* sin_t;
+  const int32_t* text_len;  /* cross: [B] */
+} dia_dec_prefill_args;
+int dia_dec_prefill_embed(const dia_dec_prefill_args* a, void* stream);
+int dia_dec_prefill_kv(const dia_dec_prefill_args* a, void* stream);
+int dia_dec_prefill_attn(const dia_dec_prefill_args* a, void* stream);
+
 /* Encoder helper: RoPE(k) and v of all L tokens from the qkv rows into an fp32 [heads][cap][128]
  * scratch "cache" (layers.py:274-279,306-307 for the encoder). */
 int dia_enc_kv_prep(const float* qkv, int ldq, int k_off, int v_off, int heads, int L, int cap,

@@ -409,3 +409,67 @@ def test_callers_cli_adapter_and_chunk_chain(mid, tmp_path):
                                 audio_prompt_texts=[plan[0][0]])[0]
     assert len(parts) == 2 and np.array_equal(parts[1], second) and second.shape[-1] > 0
     assert CL.generate_long.__doc__ and dia.dac_model is None
+
+
+def test_audio_prompt_batched_prefill_bf16(mid, monkeypatch):
+    """bf16 caches: the prompt rows run as one packed batch through the MFMA-tiled GEMMs and the
+    dia_dec_prefill_* kernels instead of being replayed step by step.  Same semantics: caches and the logits of
+    the first sampled step agree with the replay to bf16-cache accuracy, and with the fp32 oracle within the
+    bound stated for bf16 K/V (test_bf16_kv_mode_mid)."""
+    cfg, sd, w = mid
+    dm = O.Dims.of(cfg)
+    rs = np.random.RandomState(8)
+    prompts = [rs.randint(0, 1024, size=(7, dm.C)).astype(np.int32), None, rs.randint(0, 1024, size=(45, dm.C)).astype(np.int32),
+               rs.randint(0, 1024, size=(1, dm.C)).astype(np.int32)]
+    texts = TEXTS + [TEXTS[1]]
+    ptexts = ["[S1] A prompt transcript.", None, "[S2] Another one, a bit longer.", "[S1] One frame."]
+    mt, seeds = 64, [42, 7, 123, 5]
+    nzs = [O.exp_noise(sd_, mt - 1, dm.C, dm.tgt_vocab) for sd_ in seeds]
+    ids = [encode_text(effective_text(t, pt), cfg) for t, pt in zip(texts, ptexts)]
+
+    def first_logits(replay):
+        if replay:
+            monkeypatch.setenv("DIA_PROMPT_REPLAY", "1")
+        else:
+            monkeypatch.delenv("DIA_PROMPT_REPLAY", raising=False)
+        s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=mt, noise=torch.stack(nzs), audio_prompts=prompts)
+        assert s.first_steps == [8, 1, 46, 2]
+        s.prefill(); s.sync()
+        assert s._prompt_prefill_batched() == (not replay)
+        cur0 = s.cur.cpu().tolist()
+        assert cur0 == ([1, 1, 1, 1] if replay else [8, 1, 46, 1])           # a one-frame prompt stays on the replay path
+        got = {}
+        for _ in range(mt - 1):
+            cur = s.cur.cpu().tolist()
+            s.decode(1, use_graph=False)
+            lg = s.logits_host()
+            for b in range(len(ids)):
+                if cur[b] == s.first_steps[b] and b not in got:
+                    got[b] = lg[b].copy()
+            if len(got) == len(ids):
+                break
+        kv = [(s.k_self[li].float().cpu(), s.v_self[li].float().cpu()) for li in (0, len(s.k_self) - 1)]
+        res = None
+        s.close()
+        return got, kv
+
+    gb, kvb = first_logits(False)
+    gr, kvr = first_logits(True)
+    from dia_hip import layout as lay
+    worst, same, total = 0.0, 0, 0
+    for (ka, va), (kb_, vb_) in zip(kvb, kvr):
+        va, vb_ = lay.v_from_blocked(va.reshape(va.shape[0], va.shape[1], -1, 128, 32)), lay.v_from_blocked(vb_.reshape(vb_.shape[0], vb_.shape[1], -1, 128, 32))
+        for a_, b_ in ((ka, kb_), (va, vb_)):
+            for r, n in ((0, 7), (1, 7), (4, 45), (5, 45)):          # cache rows 2b + c, slots of the prompt rows
+                x, y = a_[r][:, :n], b_[r][:, :n]
+                worst = max(worst, ((x - y).abs().max() / y.abs().max()).item())
+                same += int((x == y).sum()); total += x.numel()
+    print(f"batched vs replayed prompt K/V: worst rel diff {worst:.2e}, identical {same / total:.4f}")
+    assert worst <= 0.02 and same / total >= 0.99                     # rare one-ulp bf16 flips only
+    for b in gb:
+        assert np.abs(gb[b] - gr[b]).max() <= 2e-2, b
+    torch.set_num_threads(cpu_threads())
+    for b in (0, 2):
+        r = O.generate(sd, cfg, texts[b], max_tokens=mt, noise=nzs[b], mirror=False, audio_prompt=prompts[b], audio_prompt_text=ptexts[b],
+                       max_steps=1)
+        assert np.abs(gb[b] - r.logits[0]).max() <= 5e-2, b
