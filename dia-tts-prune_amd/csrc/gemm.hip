@@ -949,6 +949,168 @@ __global__ __launch_bounds__(GT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE,
   }
 }
 
+// Wave-specialised form of k_gemm_tile: 8 consumer waves (the 2 x 4 grid above: weight tiles + MFMA only) and
+// 2 producer waves that do nothing but stage the activation planes global -> registers -> LDS.  vmcnt retires in
+// order, so in the plain form the wait for a staged chunk also waits for the weight tiles requested just before
+// it, and a chunk lasts about one memory latency; here the producers' counter sees A loads only and the
+// consumers never wait for A at all — the two kinds of wave meet at the chunk barrier.
+template <int GT_KC, int PD, int NPW>
+__global__ __launch_bounds__((8 + NPW) * 64) void k_gemm_tile_ws(GemmK p) {
+  constexpr int NWC = 8, NPROD = NPW * 64;       // NPW producer waves
+  constexpr size_t ABUF = gt_abuf(GT_KC);
+  constexpr int NPIECE = GT_KC * DIA_NPLANES * GT_MT * 64 / NPROD;     // 16-byte pieces per producer thread and chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* abuf = reinterpret_cast<u32x4*>(smem_raw);                     // [2][KC][3][MT][64] x 16 B
+  float* tiles = reinterpret_cast<float*>(smem_raw + 2 * ABUF);          // [NWC][2][16][17]
+  float* inv_s = tiles + NWC * 2 * 16 * 17;                              // [64]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int mt0 = blockIdx.y * GT_MT;
+  const int mtiles = (p.M + 15) >> 4;
+  const int nchunks = p.KT / GT_KC;
+
+  // RMSNorm scale of the 64 rows (8 threads per row sum the strip partials in fixed order)
+  for (int t = tid; t < 64 * 8; t += (NWC + NPW) * 64) {
+    const int r = t >> 3, part = t & 7, row = mt0 * 16 + r;
+    float sA = 0.f;
+    if (p.ssq_in != nullptr && row < p.M)
+      for (int i = part; i < p.ssq_in_n; i += 8) sA += p.ssq_in[(long)i * p.ssq_ld + row];
+    sA += __shfl_xor(sA, 1, 64);
+    sA += __shfl_xor(sA, 2, 64);
+    sA += __shfl_xor(sA, 4, 64);
+    if (part == 0) inv_s[r] = (p.ssq_in != nullptr) ? rsqrtf(sA * p.inv_d + p.eps) : 1.0f;
+  }
+
+  if (w >= NWC) {
+    // ================= producers =================
+    const int pt = tid - NWC * 64;
+    const u32x4* asrc[NPIECE];
+    int adst[NPIECE];
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int i = pt + NPROD * j;
+      const int ln = i & 63, blk = i >> 6, mt = blk & 3, pl = (blk >> 2) % 3, kk = blk / 12;
+      const int mtile = min(mt0 + mt, mtiles - 1);
+      asrc[j] = reinterpret_cast<const u32x4*>(p.A + pl * p.a_plane_stride + (((long)mtile * p.a_ktiles + kk) * 64 + ln) * 8);
+      adst[j] = ((kk * DIA_NPLANES + pl) * GT_MT + mt) * 64 + ln;
+    }
+    auto a_load = [&](u32x4 (&r)[NPIECE], int chunk) {
+#pragma unroll
+      for (int j = 0; j < NPIECE; ++j) r[j] = asrc[j][(long)chunk * GT_KC * 64];
+    };
+    auto a_store = [&](const u32x4 (&r)[NPIECE], int buf) {
+#pragma unroll
+      for (int j = 0; j < NPIECE; ++j) abuf[buf * (ABUF / 16) + adst[j]] = r[j];
+    };
+    u32x4 r0[NPIECE], r1[NPIECE];
+    a_load(r0, 0);
+    if (nchunks > 1) a_load(r1, 1);
+    a_store(r0, 0);
+    lds_barrier();                                    // chunk 0 staged (all 10 waves)
+    for (int c = 0; c < nchunks; c += 2) {
+      // during chunk c: chunk c+1 goes to buffer 1, chunk c+2 is requested
+      if (c + 2 < nchunks) a_load(r0, c + 2);
+      if (c + 1 < nchunks) a_store(r1, 1);
+      lds_barrier();                                  // end of chunk c
+      if (c + 1 < nchunks) {
+        if (c + 3 < nchunks) a_load(r1, c + 3);
+        if (c + 2 < nchunks) a_store(r0, 0);
+        lds_barrier();                                // end of chunk c+1
+      }
+    }
+    return;
+  }
+
+  // ================= consumers =================
+  const int wr = w >> 2, wc = w & 3;
+  const int s0 = blockIdx.x * 16 + wc * GT_WS;
+  const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + lane;
+  long woff[GT_WS];
+#pragma unroll
+  for (int j = 0; j < GT_WS; ++j) woff[j] = (long)min(s0 + j, p.nstrips - 1) * p.KT * 64;
+  auto b_load = [&](bf16x8 (&b)[GT_KC][GT_WS], int chunk) {
+#pragma unroll
+    for (int kk = 0; kk < GT_KC; ++kk)
+#pragma unroll
+      for (int j = 0; j < GT_WS; ++j) b[kk][j] = Wl[woff[j] + (long)(chunk * GT_KC + kk) * 64];
+  };
+  bf16x8 bq[PD][GT_KC][GT_WS];
+#pragma unroll
+  for (int j = 0; j < PD; ++j) if (j < nchunks) b_load(bq[j], j);
+  f32x4 acc[GT_WM][GT_WS];
+#pragma unroll
+  for (int i = 0; i < GT_WM; ++i)
+#pragma unroll
+    for (int j = 0; j < GT_WS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lds_barrier();                                      // chunk 0 staged; the weight loads stay in flight
+  auto chunk_body = [&](int c, auto Q) {
+    constexpr int q = decltype(Q)::value;
+    const u32x4* ab = abuf + (q & 1) * (ABUF / 16);
+#pragma unroll
+    for (int kk = 0; kk < GT_KC; ++kk)
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl)
+#pragma unroll
+        for (int i = 0; i < GT_WM; ++i) {
+          const u32x4 av = ab[((kk * DIA_NPLANES + pl) * GT_MT + wr * GT_WM + i) * 64 + lane];
+          const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+          for (int j = 0; j < GT_WS; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[q][kk][j], acc[i][j], 0, 0, 0);
+        }
+    if (c + PD < nchunks) b_load(bq[q], c + PD);
+    lds_barrier();
+  };
+  static_assert(PD == 2 || PD == 4, "ring depth");
+  for (int c0 = 0; c0 < nchunks; c0 += PD) {
+    chunk_body(c0, std::integral_constant<int, 0>{});
+    if (c0 + 1 < nchunks) chunk_body(c0 + 1, std::integral_constant<int, 1>{});
+    if constexpr (PD == 4) {
+      if (c0 + 2 < nchunks) chunk_body(c0 + 2, std::integral_constant<int, 2>{});
+      if (c0 + 3 < nchunks) chunk_body(c0 + 3, std::integral_constant<int, 3>{});
+    }
+  }
+  // ---- epilogue (as k_gemm_tile)
+  float* tw = tiles + w * (2 * 16 * 17);
+  const int et = lane >> 5, e_r = (lane >> 1) & 15, half = lane & 1;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < GT_WM; ++i) {
+#pragma unroll
+    for (int pr = 0; pr < GT_WS / 2; ++pr) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tw[j * (16 * 17) + (r0 + r) * 17 + col] = acc[i][2 * pr + j][r];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int mtl = wr * GT_WM + i;
+      const int m = (mt0 + mtl) * 16 + e_r;
+      const int strip = s0 + 2 * pr + et;
+      const bool live = m < p.M && strip < p.nstrips;
+      const int n0 = strip * 16 + half * 8;
+      float xpre[8], gpre[8];
+      if (p.epi == DIA_EPI_RESID_EMIT && live) {
+        const float* o = p.out + (long)m * p.ldo + n0;
+        const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+        xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+        xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) gpre[jj] = p.gnext ? p.gnext[n0 + jj] : 1.0f;
+      }
+      run_epilogue(p, tw + et * (16 * 17) + e_r * 17, inv_s[mtl * 16 + e_r], m, n0, half, min(strip, p.nstrips - 1), live, xpre, gpre);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+template <int KC, int PD, int NPW>
+int launch_tile_ws(const GemmK& k, hipStream_t st) {
+  const int mgroups = ((k.M + 15) / 16 + GT_MT - 1) / GT_MT;
+  launch_kernel(k_gemm_tile_ws<KC, PD, NPW>, dim3((k.nstrips + 15) / 16, mgroups), dim3((8 + NPW) * 64), gt_smem(KC, 8), st, k);
+  return dia_check_launch("k_gemm_tile_ws");
+}
+
 template <int KC, int PD, int WPE, int NWT>
 int launch_tile_v(const GemmK& k, hipStream_t st) {
   const int mgroups = ((k.M + 15) / 16 + GT_MT - 1) / GT_MT;
@@ -960,13 +1122,16 @@ int launch_tile_v(const GemmK& k, hipStream_t st) {
 int launch_tile(const GemmK& k, hipStream_t st) {
   int rc = dia_kernels_init_once();
   if (rc) return rc;
-  // 8 waves / 64 x 256 blocks when they fill the chip (wi 137 vs 192 us at 1696 rows); narrow outputs (o, wo:
-  // N = 1024 -> 4 column blocks) get 4 waves / 64 x 128 blocks, twice the workgroups (wo 86 vs 97 us)
-  const int blocks8 = (((k.M + 15) / 16 + GT_MT - 1) / GT_MT) * ((k.nstrips + 15) / 16);
-  int v = blocks8 < 192 ? 1 : 0;
+  // default: the wave-specialised form (8 consumer + 4 producer waves): wi 113 us, wo 79, qkv 52, o 29 at 1696
+  // rows, against 137 / 97 / 61 / 34 for the plain 8-wave form and 192 / 86 / 79 / 30 for 4-wave 64 x 128
+  // blocks (kept behind DIA_DBG_TILE_V = 0 / 1 for comparison)
+  int v = 3;
   if (const char* e = getenv("DIA_DBG_TILE_V")) v = atoi(e);
   if (v == 1) return launch_tile_v<2, 4, 1, 4>(k, st);
   if (v == 2) return launch_tile_v<2, 2, 1, 4>(k, st);
+  if (v == 3) return launch_tile_ws<2, 2, 4>(k, st);
+  if (v == 4) return launch_tile_ws<2, 2, 2>(k, st);
+  if (v == 5) return launch_tile_ws<2, 4, 4>(k, st);
   return launch_tile_v<2, 4, 2, 8>(k, st);
 }
 
@@ -1145,6 +1310,9 @@ int dia_gemm_init() {
   int rc = 0;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fused<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_smem(64, 128)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fused<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_smem(16, 16)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile_ws<2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile_ws<2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile_ws<2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 4, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 4, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 4)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 4)) != hipSuccess) rc = 1;
