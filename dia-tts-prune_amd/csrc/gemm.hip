@@ -1160,6 +1160,7 @@ int launch_g16_any(const GemmK& k, int nw, int sk, hipStream_t st, bool& handled
     if (kpw == 2) return launch_g16<16, 2>(k, st);
     if (kpw == 4) return launch_g16<16, 4>(k, st);
   } else if (nw == 8) {
+    if (kpw == 1) return launch_g16<8, 1>(k, st);
     if (kpw == 2) return launch_g16<8, 2>(k, st);
     if (kpw == 3) return launch_g16<8, 3>(k, st);
     if (kpw == 4) return launch_g16<8, 4>(k, st);
@@ -1257,6 +1258,9 @@ int launch_small_rs(const GemmK& k, int nw, int sk, hipStream_t st, bool& handle
     if (kpw == 6) return launch_small<8, 6, RS>(k, st);
     if (kpw == 7) return launch_small<8, 7, RS>(k, st);
     if (kpw == 8) return launch_small<8, 8, RS>(k, st);
+    if (kpw == 10) return launch_small<8, 10, RS>(k, st);    // 10, 12, 14: compacted hidden widths (multiples of 1024) under split-K 2
+    if (kpw == 12) return launch_small<8, 12, RS>(k, st);
+    if (kpw == 14) return launch_small<8, 14, RS>(k, st);
     if (kpw == 16) return launch_small<8, 16, RS>(k, st);
     if (kpw == 32) return launch_small<8, 32, RS>(k, st);
   } else if (nw == 16) {
@@ -1317,7 +1321,7 @@ int dia_gemm_init() {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 4, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 4)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile<2, 2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 4)) != hipSuccess) rc = 1;
   rc |= small_attr<4, 4>(); rc |= small_attr<4, 8>(); rc |= small_attr<4, 16>();
-  rc |= small_attr<8, 2>(); rc |= small_attr<8, 3>(); rc |= small_attr<8, 4>(); rc |= small_attr<8, 5>(); rc |= small_attr<8, 6>(); rc |= small_attr<8, 7>(); rc |= small_attr<8, 8>(); rc |= small_attr<8, 16>(); rc |= small_attr<8, 32>();
+  rc |= small_attr<8, 2>(); rc |= small_attr<8, 3>(); rc |= small_attr<8, 4>(); rc |= small_attr<8, 5>(); rc |= small_attr<8, 6>(); rc |= small_attr<8, 7>(); rc |= small_attr<8, 8>(); rc |= small_attr<8, 10>(); rc |= small_attr<8, 12>(); rc |= small_attr<8, 14>(); rc |= small_attr<8, 16>(); rc |= small_attr<8, 32>();
   rc |= small_attr<16, 1>(); rc |= small_attr<16, 2>(); rc |= small_attr<16, 4>(); rc |= small_attr<16, 8>();
   return rc ? DIA_E_HIP : DIA_OK;
 }

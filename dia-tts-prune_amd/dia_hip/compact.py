@@ -131,11 +131,25 @@ def pad_hidden_keep(live_hidden: torch.Tensor) -> torch.Tensor:
     """indices of the live hidden units (int64), their count padded up to a multiple of K_GRANULE (8 for toy sizes) with -1
     (zero gate/up columns in wi, zero rows in wo)"""
     idx = torch.nonzero(live_hidden).flatten()
-    granule = K_GRANULE if (live_hidden.numel() >= 2048 and live_hidden.numel() % K_GRANULE == 0) else 8   # small models: whole strips only
+    # full-size models: whole multiples of 1024 hidden units = 32 k-tiles of wo's K, which every split-K form of
+    # the fast kernels divides (a 30 %-pruned 5734 -> 6144; 5888 would fall to the generic kernel); small
+    # models: whole 16-column strips only
+    granule = 4 * K_GRANULE if (live_hidden.numel() >= 4096 and live_hidden.numel() % (4 * K_GRANULE) == 0) else \
+        (K_GRANULE if (live_hidden.numel() >= 2048 and live_hidden.numel() % K_GRANULE == 0) else 8)
     pad = (-idx.numel()) % granule
     if pad:
         idx = torch.cat([idx, torch.full((pad,), -1, dtype=idx.dtype, device=idx.device)])
     return idx
+
+
+def pad_rows(w2d: torch.Tensor, granule: int = K_GRANULE) -> torch.Tensor:
+    """zero rows appended up to a multiple of `granule`: the K of o_proj after dead heads are dropped is
+    live_heads * 128 (11 heads -> 1408 rows = 44 k-tiles, which no fast kernel divides); the extra rows meet
+    activation-plane columns that nobody writes (zero), so they add exactly nothing."""
+    pad = (-w2d.shape[0]) % granule
+    if pad == 0:
+        return w2d
+    return torch.cat([w2d, torch.zeros(pad, w2d.shape[1], dtype=w2d.dtype, device=w2d.device)], dim=0)
 
 
 def take_rows(w2d: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:

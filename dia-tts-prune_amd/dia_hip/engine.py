@@ -90,7 +90,7 @@ class DeviceWeights:
                 hc = P.live_heads.to(device).repeat_interleave(HEAD_DIM)            # live head columns
                 kq = P.keep_qkv.to(device)
                 wq, wk, wv = wq[kq][:, hc], wk[kq][:, hc], wv[kq][:, hc]
-                o = o[hc]
+                o = cpt.pad_rows(o[hc])
                 hid = cpt.pad_hidden_keep(P.live_hidden).to(device)
                 wi3 = torch.stack([cpt.take_cols_idx(wi3[:, 0, :], hid), cpt.take_cols_idx(wi3[:, 1, :], hid)], dim=1)
                 wi3 = wi3[P.keep_wi.to(device)]
@@ -148,10 +148,10 @@ class DeviceWeights:
                 s_qkv = (cpt.strips_of_heads(P.live_q_heads, 0) + cpt.strips_of_heads(P.live_kv_heads, QH * 128)
                          + cpt.strips_of_heads(P.live_kv_heads, (QH + KVH) * 128))
                 qkv = qkv[P.keep_qkv.to(device)][:, cols(s_qkv)]
-                o = o[P.live_q_heads.to(device).repeat_interleave(128)]
+                o = cpt.pad_rows(o[P.live_q_heads.to(device).repeat_interleave(128)])
                 s_cq = cpt.strips_of_heads(P.live_c_heads, 0)
                 cq = cq[P.keep_cq.to(device)][:, cols(s_cq)]
-                co = co[P.live_c_heads.to(device).repeat_interleave(128)]
+                co = cpt.pad_rows(co[P.live_c_heads.to(device).repeat_interleave(128)])
                 s_ckv = cpt.strips_of_heads(P.live_c_heads, 0) + cpt.strips_of_heads(P.live_c_heads, CH * 128)
                 ckv = ckv[:, cols(s_ckv)]
                 hid = cpt.pad_hidden_keep(P.live_hidden).to(device)
@@ -432,7 +432,7 @@ class DecodeSession:
                 Lmax = _ceil(max(self.lens), 16)
                 Hmax = max(EL["heads"] for EL in w.enc_layers)
                 ekt = E // 32
-                akt = max(1, Hmax * HEAD_DIM // 32)
+                akt = max(max(1, Hmax * HEAD_DIM // 32), max(EL["o"].kt for EL in w.enc_layers))   # o rows may be zero-padded
                 hkt = max(EL["wo"].kt for EL in w.enc_layers)                 # (compacted) hidden width in k-tiles
                 z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)
                 x = z(Mp, E)

@@ -170,10 +170,15 @@ def test_compaction_plan_from_zeros():
     idx = cpt.pad_hidden_keep(torch.tensor([True] * 5 + [False] * 11))
     assert idx.tolist() == [0, 1, 2, 3, 4, -1, -1, -1]
     big = torch.zeros(4096, dtype=torch.bool); big[:300] = True
-    assert cpt.pad_hidden_keep(big).numel() == 512 and int((cpt.pad_hidden_keep(big) < 0).sum()) == 212
+    assert cpt.pad_hidden_keep(big).numel() == 1024 and int((cpt.pad_hidden_keep(big) < 0).sum()) == 724   # 4096-wide: 1024 granule
+    mid_ = torch.zeros(2048, dtype=torch.bool); mid_[:300] = True
+    assert cpt.pad_hidden_keep(mid_).numel() == 512
     k = torch.zeros(2048, dtype=torch.bool); k[100:300] = True
     pk = cpt.pad_keep(k)                                  # full-size K: 256-row granule
     assert int(pk.sum()) == 256 and pk[100:300].all() and pk[:56].all() and not pk[56:100].any()
+    w_ = torch.randn(1408, 8)
+    pw = cpt.pad_rows(w_)                                 # 11 heads x 128 rows -> 1536: zero rows appended
+    assert pw.shape == (1536, 8) and torch.equal(pw[:1408], w_) and (pw[1408:] == 0).all() and cpt.pad_rows(pw) is pw
     k2 = torch.zeros(512, dtype=torch.bool); k2[100:300] = True
     assert int(cpt.pad_keep(k2).sum()) == 224             # small models: whole k-tiles only
     dense = cpt.plan_decoder_layer(sd, pre, d.gqa_query_heads, d.kv_heads, d.cross_query_heads)
