@@ -182,7 +182,7 @@ def chunk_goldens():
             cs = ns["auto_adjust_chunk_size"](t, user)
             chunks = ns["split_by_words_respecting_special_tokens"](t, max_effective_chars=cs)
             rec[f"cs_{i}_{user}"] = np.int32(cs)
-            rec[f"chunks_{i}_{user}"] = np.array(chunks, dtype=object) if False else np.array(["\x00".join(chunks)])
+            rec[f"chunks_{i}_{user}"] = np.array(["\x00".join(chunks)])       # one NUL-joined string: no pickled object arrays
             rec[f"batches_{i}_{user}"] = np.array([len(b) for b in ns["batch_chunks"](chunks, 4)], dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, "ref_chunks.npz"), **rec)
     print("ref_chunks.npz written")
