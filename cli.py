@@ -31,30 +31,30 @@ def set_seed(seed: int):
 
 
 def build_parser() -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser(description="Generate audio using the Dia model via CLI.")
-    p.add_argument("text", type=str, help="Input text for speech generation. If using --audio-prompt, this should be the text to *generate*, not the prompt transcript.")
-    p.add_argument("--output", type=str, default=None, help="Path to save the generated audio file (e.g., output.wav).")
+    p = argparse.ArgumentParser(description="Dia text-to-dialogue on MI355X: text in, audio (or codec codes) out.")
+    p.add_argument("text", type=str, help="text to synthesise ([S1]/[S2] speaker tags); with --audio-prompt give only the new text here, the prompt transcript goes to --audio-prompt-text")
+    p.add_argument("--output", type=str, default=None, help="audio file to write (needs the codec)")
     p.add_argument("--codes-output", type=str, default=None, help="(build-only) path for the codec input codes [1, C, T] as .npy")
     g = p.add_argument_group("Model Loading")
-    g.add_argument("--model-path", type=str, default="nari-labs/Dia-1.6B", help="Local path to a model directory (containing config.json and pytorch_model.bin); a hub id cannot be fetched offline.")
-    g.add_argument("--config", type=str, default=None, help="Path to local config.json file (overrides config found in --model-path if provided).")
-    g.add_argument("--pruned-checkpoint", type=str, default=None, help="Path to a specific (potentially pruned) model checkpoint .bin file (overrides checkpoint found in --model-path).")
-    g.add_argument("--adapter-path", type=str, default=None, help="Path to LoRA adapter directory; merged into the dense weights at load.")
+    g.add_argument("--model-path", type=str, default="nari-labs/Dia-1.6B", help="model directory holding config.json and the checkpoint (hub ids cannot be fetched offline)")
+    g.add_argument("--config", type=str, default=None, help="config.json to use instead of the one in --model-path")
+    g.add_argument("--pruned-checkpoint", type=str, default=None, help="checkpoint file to load instead of the one in --model-path, e.g. an offline_prune.py output")
+    g.add_argument("--adapter-path", type=str, default=None, help="LoRA adapter directory; folded into the dense weights while loading")
     g.add_argument("--no-dac", action="store_true", help="(build-only) do not load the audio codec; requires --codes-output")
     g = p.add_argument_group("Audio Prompting (Voice Cloning)")
-    g.add_argument("--audio-prompt", type=str, default=None, help="Path to an audio prompt WAV/MP3 file for voice cloning, or a .npy file of codes [T, 9].")
-    g.add_argument("--audio-prompt-text", type=str, default=None, help="Required: Exact transcript of the --audio-prompt file.")
+    g.add_argument("--audio-prompt", type=str, default=None, help="voice to clone: an audio file (needs the codec) or a .npy of codec codes [T, 9]")
+    g.add_argument("--audio-prompt-text", type=str, default=None, help="what is said in --audio-prompt (mandatory with it)")
     g = p.add_argument_group("Generation Parameters")
-    g.add_argument("--max-tokens", type=int, default=None, help="Maximum number of audio tokens to generate (defaults to config value).")
-    g.add_argument("--cfg-scale", type=float, default=3.0, help="Classifier-Free Guidance scale (default: 3.0).")
-    g.add_argument("--temperature", type=float, default=1.3, help="Sampling temperature (higher is more random, default: 1.3).")
-    g.add_argument("--top-p", type=float, default=0.95, help="Nucleus sampling probability (default: 0.95).")
-    g.add_argument("--cfg-filter-top-k", type=int, default=35, help="Top-K filter for CFG (0 to disable, default: 35).")
-    g.add_argument("--seed", type=int, default=None, help="Random seed for reproducibility.")
+    g.add_argument("--max-tokens", type=int, default=None, help="cap on generated frames incl. the prompt (default: audio_length of the config)")
+    g.add_argument("--cfg-scale", type=float, default=3.0, help="classifier-free guidance strength")
+    g.add_argument("--temperature", type=float, default=1.3, help="softmax temperature of the sampler; 0 = greedy")
+    g.add_argument("--top-p", type=float, default=0.95, help="nucleus (top-p) mass kept by the sampler")
+    g.add_argument("--cfg-filter-top-k", type=int, default=35, help="keep only the k best logits after guidance; 0 switches the filter off")
+    g.add_argument("--seed", type=int, default=None, help="seed of the sampling noise")
     g = p.add_argument_group("Infrastructure")
-    g.add_argument("--device", type=str, default=None, help="HIP device (e.g. 'cuda:0', default: current device).")
+    g.add_argument("--device", type=str, default=None, help="HIP device such as cuda:0 (default: the current one)")
     g.add_argument("--compute-dtype", type=str, default="bfloat16", choices=["float16", "bfloat16", "float32"], help="K/V cache dtype: bfloat16 (default; float16 is accepted and mapped to it) or float32.")
-    g.add_argument("--verbose", action="store_true", help="Print verbose generation progress.")
+    g.add_argument("--verbose", action="store_true", help="report prefill and generation timing")
     return p
 
 
@@ -62,9 +62,9 @@ def main(argv=None) -> int:
     parser = build_parser()
     args = parser.parse_args(argv)
     if args.audio_prompt and not args.audio_prompt_text:
-        parser.error("--audio-prompt-text is required when using --audio-prompt.")
+        parser.error("--audio-prompt needs its transcript: pass --audio-prompt-text")
     if args.pruned_checkpoint and not args.config and not Path(args.model_path).is_dir():
-        parser.error("--config is required when using --pruned-checkpoint with a non-local --model-path (e.g., HF repo ID).")
+        parser.error("--pruned-checkpoint needs --config unless --model-path is a local directory with a config.json")
     if not args.output and not args.codes_output:
         parser.error("one of --output / --codes-output is required.")
     if args.no_dac and args.output:

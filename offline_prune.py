@@ -22,15 +22,15 @@ sys.path.insert(0, os.path.join(ROOT, "dia-tts-prune_amd"))
 
 
 def main(argv=None) -> int:
-    p = argparse.ArgumentParser(description="Apply offline pruning to a Dia model.")
-    p.add_argument("--model-path", type=str, required=True, help="Local model directory (config.json + pytorch_model.bin / model.safetensors).")
-    p.add_argument("--output-dir", type=str, required=True, help="Directory to save the pruned model checkpoint and config.")
-    p.add_argument("--prune-mode", type=str, required=True, choices=["unstructured", "structured"], help="Pruning mode.")
-    p.add_argument("--prune-amount", type=float, required=True, help="Fraction of weights/structures to prune (0.0 to 1.0).")
-    p.add_argument("--prune-dim", type=int, default=0, help="Dimension to prune along for structured pruning.")
-    p.add_argument("--prune-norm", type=int, default=2, choices=[1, 2], help="Norm (L1 or L2) for structured pruning importance.")
+    p = argparse.ArgumentParser(description="Prune a Dia checkpoint on the CPU and write it back with the zeros baked in.")
+    p.add_argument("--model-path", type=str, required=True, help="directory of the dense model: config.json plus its checkpoint")
+    p.add_argument("--output-dir", type=str, required=True, help="where pytorch_model.bin and config.json of the pruned model go")
+    p.add_argument("--prune-mode", type=str, required=True, choices=["unstructured", "structured"], help="global magnitude pruning of single weights, or whole slices along --prune-dim")
+    p.add_argument("--prune-amount", type=float, required=True, help="share of weights (unstructured) or of slices per matrix (structured) to zero, strictly between 0 and 1")
+    p.add_argument("--prune-dim", type=int, default=0, help="structured mode: the axis whose slices are ranked and zeroed")
+    p.add_argument("--prune-norm", type=int, default=2, choices=[1, 2], help="structured mode: rank slices by their L1 or L2 norm")
     p.add_argument("--device", type=str, default="cpu", help="accepted for compatibility; the tool runs on the CPU")
-    p.add_argument("--compute-dtype", type=str, default="float32", choices=["float32"], help="Compute dtype (must be float32 for pruning).")
+    p.add_argument("--compute-dtype", type=str, default="float32", choices=["float32"], help="pruning arithmetic is float32")
     a = p.parse_args(argv)
     if not (0.0 < a.prune_amount < 1.0):
         print("Error: --prune-amount must be between 0.0 and 1.0 (exclusive).")
