@@ -473,3 +473,27 @@ def test_audio_prompt_batched_prefill_bf16(mid, monkeypatch):
         r = O.generate(sd, cfg, texts[b], max_tokens=mt, noise=nzs[b], mirror=False, audio_prompt=prompts[b], audio_prompt_text=ptexts[b],
                        max_steps=1)
         assert np.abs(gb[b] - r.logits[0]).max() <= 5e-2, b
+
+
+@pytest.mark.parametrize("amount", [0.3, 0.7])
+def test_structured_pruned_odd_ratios_match_oracle(mid, amount):
+    """pruning ratios that leave awkward shapes (6 of 8 heads, keep sets and hidden widths that need zero
+    padding): the compacted model still equals the oracle run on the same (zero-holding) checkpoint."""
+    from dia_hip.pruning import structured_prune_state_dict
+    cfg, sd, _ = mid
+    psd, _ = structured_prune_state_dict(cfg, sd, amount=amount, dim=0, n=2)
+    dev = torch.device("cuda:0")
+    wc = DeviceWeights(cfg, psd, dev)
+    assert wc.compacted and wc.enc_compacted
+    mt = 30
+    r, nz = oracle_run(cfg, psd, TEXTS[0], 42, mt)
+    logits, res = teacher_forced(wc, cfg, [TEXTS[0]], [r.tokens], [nz], mt)
+    worst = max(float(np.abs(logits[i][0] - r.logits[i]).max()) for i in range(len(r.logits)))
+    print(f"pruned {amount}: logits max-abs err {worst:.3e}")
+    assert worst <= LOGIT_TOL
+    for i, p in enumerate(r.preds):
+        assert np.array_equal(res[0].preds[1 + i], p), i
+    s = DecodeSession(wc, [encode_text(effective_text(TEXTS[0]), cfg)], kv_dtype="f32", max_tokens=mt, seeds=[42])
+    s.prefill(); s.run(use_graph=True, poll=8)
+    out = s.results()[0]; s.close()
+    assert np.array_equal(out.tokens, r.tokens)
