@@ -231,6 +231,27 @@ def test_full_size_first_steps_vs_oracle():
         outs.append((s.results()[0].tokens.copy(), s.logits_host().copy()))
         s.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # audio prompt at full size, bf16 caches: batched MFMA prefill (tiled GEMMs over 2 x 128 packed rows) against the
+    # replay of the same 100 prompt rows through the decode step
+    prompt = np.random.RandomState(2).randint(0, 1024, size=(100, 9)).astype(np.int32)
+    ids = [encode_text(effective_text(TEXTS[1], "[S1] The prompt."), cfg)]
+    firsts = []
+    for replay in ("0", "1"):
+        os.environ["DIA_PROMPT_REPLAY"] = replay
+        try:
+            s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=110, seeds=[1], audio_prompts=[prompt], ignore_eos=True)
+            s.prefill(); s.sync()
+            assert s._prompt_prefill_batched() == (replay == "0")
+            s.decode(101 - int(s.cur[0].item()) + 1, use_graph=False)          # up to and including step 101 = first_step
+            s.sync()
+            assert int(s.cur[0].item()) == 102
+            firsts.append(s.logits_host()[0].copy())
+            s.close()
+        finally:
+            os.environ.pop("DIA_PROMPT_REPLAY", None)
+    err = float(np.abs(firsts[0] - firsts[1]).max())
+    print(f"Dia-1.6B audio prompt (100 frames): first sampled logits, batched prefill vs replay: {err:.3e}")
+    assert err <= 2e-2
 
 
 def test_structured_pruned_checkpoint_is_compacted_and_matches_reference(mid, golden):
