@@ -136,6 +136,9 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     int wo_sk = (R <= 4 && L.kt_wo % 2 == 0) ? 2 : ((R <= 16 && L.kt_wo % 4 == 0) ? 4 : 1);
     if (const char* ev = getenv("DIA_DBG_WO_SK")) wo_sk = atoi(ev) >= 1 && atoi(ev) <= 4 ? atoi(ev) : wo_sk;
     g.sk = wo_sk; g.sk_scratch = wo_sk > 1 ? d.sk_scratch : nullptr; g.sk_tickets = wo_sk > 1 ? d.sk_tickets : nullptr;
+    if (R > 16 && R <= 32) {      // two m-tiles: dia_gemm splits K = 8192 four ways by itself (k_gemm32)
+      g.sk = 1; g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets; g.sk_scratch_floats = (int64_t)(d.D / 16) * 4 * 512;
+    }
     if (const char* ev = getenv("DIA_DBG_WO_NW")) g.nw = atoi(ev);
     if (const char* ev = getenv("DIA_DBG_WO_SPW")) g.spw = atoi(ev);
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D;

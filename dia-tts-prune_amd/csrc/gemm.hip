@@ -793,6 +793,108 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
   }
 }
 
+// 17..32 rows (batch 9-16): two m-tiles, the k_gemm16 scheme with both tiles' A fragments in registers
+// (24 * KPW VGPRs: 8 waves x 4 k-tiles), one strip per workgroup, K split over gridDim.y workgroups whose
+// partial tiles meet through the fence-free slab hand-off (2 x 256 floats per slab).
+template <int KPW>
+__global__ __launch_bounds__(512) void k_gemm32(GemmK p) {
+  constexpr int NW = 8, MT = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                              // [NW][MT][64]
+  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * MT * 64);   // [MT][16][17]
+  float* inv_s = tile + MT * 16 * 17;                                           // [32]
+  __shared__ int sk_flag;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int strip = blockIdx.x, ks = blockIdx.y, SK = gridDim.y;
+  const int kt0 = ks * (NW * KPW) + w * KPW;
+  const int e_mt = tid >> 5, e_r = (tid >> 1) & 15, half = tid & 1;
+  const int m = e_mt * 16 + e_r;
+  const bool e_thread = tid < 32 * MT;
+  const bool live = e_thread && m < p.M;
+  float xpre[8], gpre[8];
+  // A fragments of both m-tiles (rows >= M alias the last valid row)
+  bf16x8 a[MT][KPW][DIA_NPLANES];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = min(mt * 16 + (lane & 15), p.M - 1);
+    const long aoff = ((long)(row >> 4) * p.a_ktiles * 64 + ((lane & 48) | (row & 15))) * 8;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl)
+        a[mt][i][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff + (long)(kt0 + i) * 512);
+  }
+  // row scales: 8 threads per row, 32 rows
+  {
+    const int s_row = tid >> 3, s_part = tid & 7;
+    float s0 = 0.f;
+    if (tid < 256 && p.ssq_in != nullptr && s_row < p.M)
+      for (int i = s_part; i < p.ssq_in_n; i += 8) s0 += p.ssq_in[(long)i * p.ssq_ld + s_row];
+    s0 += __shfl_xor(s0, 1, 64);
+    s0 += __shfl_xor(s0, 2, 64);
+    s0 += __shfl_xor(s0, 4, 64);
+    if (tid < 256 && s_part == 0) inv_s[s_row] = (p.ssq_in != nullptr) ? rsqrtf(s0 * p.inv_d + p.eps) : 1.0f;
+  }
+  if (p.epi == DIA_EPI_RESID_EMIT && e_thread) {
+    const int n0 = strip * 16 + half * 8;
+    const float* o = p.out + (long)(live ? m : 0) * p.ldo + n0;
+    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+    xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+    xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gpre[j] = p.gnext ? p.gnext[n0 + j] : 1.0f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  bf16x8 b[KPW];
+  {
+    const bf16x8* Wt = reinterpret_cast<const bf16x8*>(p.W) + ((long)strip * p.KT + kt0) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) b[i] = DIA_WLOAD(Wt + (long)i * 64);
+  }
+  f32x4 acc[MT] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < KPW; ++i)
+#pragma unroll
+    for (int pl = 0; pl < DIA_NPLANES; ++pl)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][i][pl], b[i], acc[mt], 0, 0, 0);
+  reduce_to_tile<MT, NW, true>(acc, red, tile, tid, lane, w);
+  if (SK > 1) {        // as splitk_combine, two tiles per slab
+    float* slab = p.sk_scratch + ((long)strip * SK + ks) * (MT * 256);
+    if (tid < MT * 128) {
+      const int t = tid >> 7, e = (tid & 127) * 2;
+      st2_agent(slab + t * 256 + e, tile[(t * 16 + (e >> 4)) * 17 + (e & 15)], tile[(t * 16 + (e >> 4)) * 17 + (e & 15) + 1]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int ticket = __hip_atomic_fetch_add(p.sk_tickets + strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == SK - 1;
+      if (last) __hip_atomic_store(p.sk_tickets + strip, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sk_flag = last;
+    }
+    __syncthreads();
+    if (!sk_flag) return;
+    if (tid < MT * 128) {
+      const int t = tid >> 7, e = (tid & 127) * 2;
+      const float* base = p.sk_scratch + (long)strip * SK * (MT * 256) + t * 256 + e;
+      float x0 = 0.f, x1 = 0.f;
+      for (int k = 0; k < SK; ++k) { const float2 v = ld2_agent(base + (long)k * (MT * 256)); x0 += v.x; x1 += v.y; }
+      tile[(t * 16 + (e >> 4)) * 17 + (e & 15)] = x0; tile[(t * 16 + (e >> 4)) * 17 + (e & 15) + 1] = x1;
+    }
+    __syncthreads();
+  }
+  if (e_thread) run_epilogue(p, tile + (e_mt * 16 + e_r) * 17, inv_s[e_mt * 16 + e_r], m, strip * 16 + half * 8, half, strip, live, xpre, gpre);
+}
+
+template <int KPW>
+int launch_g32(const GemmK& k, int sk, hipStream_t st) {
+  const size_t smem = sizeof(f32x4) * 8 * 2 * 64 + sizeof(float) * (2 * 16 * 17 + 32);
+  launch_kernel(k_gemm32<KPW>, dim3(k.nstrips, sk), dim3(512), smem, st, k);
+  return dia_check_launch("k_gemm32");
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Prefill GEMM (encoder layers, cross-K/V projections: M = text bytes, tens to thousands of rows).
 // Here the contraction is dense and MFMA is the roofline, not HBM: a workgroup owns a 64-row x 256-column
@@ -1385,6 +1487,17 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
       int rc = launch_g16_any(k, nw16, sk, st, handled);
       if (handled) return rc;
     }
+  }
+  // 17..32 rows: two m-tiles with register-resident A (8 waves x 8 k-tiles = K 2048 per workgroup); longer K is
+  // split over KT / 64 workgroups per strip when the caller's scratch holds nstrips * sk * 512 floats
+  if (mtiles == 2 && a->KT % 64 == 0 && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext) && a->sk <= 1 &&
+      !getenv("DIA_DBG_NO_G32")) {
+    const int sk32 = a->KT / 64;
+    // only the long-K case pays (wo at batch 16: 36 -> 25 us): with K = 2048 every one-strip workgroup re-reads the
+    // whole 393 KB activation image and loses to the generic kernel (wi 47 vs 38 us), so that case needs
+    // DIA_DBG_G32_ALL to be selected
+    if (sk32 == 1 && getenv("DIA_DBG_G32_ALL")) return launch_g32<8>(k, 1, st);
+    if (sk32 > 1 && a->sk_scratch && a->sk_tickets && a->sk_scratch_floats >= (int64_t)a->nstrips * sk32 * 512) return launch_g32<8>(k, sk32, st);
   }
   if (sk > 1) return dia_fail(DIA_E_ARG, "dia_gemm: no split-K kernel for this shape");
   // prefill shapes: the MFMA-tiled kernel (64 x 256 blocks) from 3 m-tiles on

@@ -42,7 +42,7 @@ class GemmArgs(C.Structure):
         ("kv_batch_index", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("cmap", C.c_void_p), ("strip_map", C.c_void_p),
         ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p), ("sk", C.c_int32), ("kv_vblocked", C.c_int32),
-        ("row_b", C.c_void_p), ("seg_off", C.c_void_p),
+        ("row_b", C.c_void_p), ("seg_off", C.c_void_p), ("sk_scratch_floats", C.c_int64),
     ]
 
 

@@ -267,7 +267,7 @@ class DecodeSession:
                   hb.lib().dia_attn_scratch_floats(B, d.cross_query_heads, self.S))
         self.attn_scratch = z(max(nsc, 1))
         self.attn_tickets = z(max(self.R * d.kv_heads, B * d.cross_query_heads), dt=torch.int32)
-        self.sk_scratch = z((self.D // 16) * 4 * 256)
+        self.sk_scratch = z((self.D // 16) * 4 * 512)      # split-K slabs: up to 4 splits of one (<= 16 rows) or two m-tiles
         self.sk_tickets = z(self.D // 16, dt=torch.int32)
         self.mlp_barrier = z(2, dt=torch.int32)          # dia_mlp_fused: arrivals, error flag
 

@@ -106,6 +106,9 @@ typedef struct {
    * position m - seg_off[row_b[m]]; both NULL = one utterance, kv_batch_index, position m. */
   const int32_t* row_b;
   const int32_t* seg_off;
+  /* capacity of sk_scratch in floats (0 = not stated: only the explicit `sk` split-K, nstrips * sk * 256 floats, is
+   * assumed).  With 17..32 rows and K > 2048 dia_gemm splits K by itself when nstrips * (KT / 64) * 512 floats fit. */
+  int64_t sk_scratch_floats;
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
@@ -332,7 +335,7 @@ typedef struct {
   const float* cos_t;       /* [T+1][64] */
   const float* sin_t;
   const int32_t* text_len;  /* [B] */
-  float* sk_scratch;        /* split-K slabs: (D/16)*4*256 floats */
+  float* sk_scratch;        /* split-K slabs: (D/16)*4*512 floats */
   int32_t* sk_tickets;      /* D/16 int32, zeroed by the caller once */
   float* attn_scratch;      /* max over self/cross of dia_attn_scratch_floats(...) floats */
   int32_t* attn_tickets;    /* max(R*kv_heads, B*cq_heads) int32, zeroed by the caller once */

@@ -129,6 +129,67 @@ def test_gemm_split_k_resid(M, K, D, sk):
     assert torch.equal(lay.unpack_planes(outs[0][1], M, D), outs[0][0] * gn)
 
 
+@pytest.mark.parametrize("M", [17, 20, 32])
+def test_gemm_two_mtiles(M, monkeypatch):
+    """17..32 rows (batch 9-16): k_gemm32 — both m-tiles' A fragments in registers; K = 2048 in one workgroup
+    (selected by a debug knob only: it loses to the generic kernel), K = 8192 split four ways by dia_gemm itself
+    when the scratch capacity is stated."""
+    monkeypatch.setenv("DIA_DBG_G32_ALL", "1")
+    d = dev()
+    torch.manual_seed(M)
+    # SCALE_STORE with the row norm, K = 2048
+    K, N = 2048, 512
+    x = torch.randn(M, K, device=d) * 2.0
+    gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
+    W = bf16r(torch.randn(K, N, device=d) * 0.05)
+    Wt, kt, ns = lay.tile_weight(W)
+    out = torch.full((M, N), float("nan"), device=d)
+    run_gemm(x * gw, Wt, kt, ns, hb.EPI_SCALE_STORE, ssq_in=strip_ssq(x, 32), inv_d=1.0 / K, eps=1e-5, out=out, ldo=N, ssq_ld=32)
+    xd = x.double()
+    ref = ((xd * gw.double()) @ W.double()) * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+    assert (out.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # SWIGLU, K = 2048
+    F = 1024
+    wi = bf16r(torch.randn(K, 2, F, device=d) * 0.05)
+    Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi))
+    P = torch.zeros(3, 2, F // 32, 64, 8, dtype=torch.bfloat16, device=d)
+    run_gemm(x * gw, Wt, kt, ns, hb.EPI_SWIGLU_EMIT, ssq_in=strip_ssq(x, 32), inv_d=1.0 / K, eps=1e-5, P=P, p_kt=F // 32, ssq_ld=32)
+    h = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
+    f = torch.einsum("mk,kgf->mgf", h, wi.double())
+    ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
+    assert (lay.unpack_planes(P, M, F).double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # RESID_EMIT, K = 8192: split-K 4 inside dia_gemm, twice for reproducibility
+    K2, D = 8192, 256
+    a = torch.randn(M, K2, device=d)
+    W2 = bf16r(torch.randn(K2, D, device=d) * 0.03)
+    x0 = torch.randn(M, D, device=d)
+    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+    Wt, kt, ns = lay.tile_weight(W2)
+    A = lay.pack_planes(a)
+    scr = torch.zeros(ns * 4 * 512, device=d); tk = torch.zeros(ns, dtype=torch.int32, device=d)
+    outs = []
+    for _ in range(2):
+        xr = x0.clone()
+        P = torch.zeros(3, 2, D // 32, 64, 8, dtype=torch.bfloat16, device=d)
+        ssq = torch.zeros(ns, 32, device=d)
+        g = hb.GemmArgs()
+        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+        g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_RESID_EMIT
+        g.ssq_ld, g.out, g.ldo, g.gnext = 32, hb.ptr(xr), D, hb.ptr(gn)
+        g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), D // 32, hb.ptr(ssq)
+        g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = hb.ptr(scr), hb.ptr(tk), scr.numel()
+        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+        torch.cuda.synchronize()
+        outs.append((xr, P, ssq))
+    assert (tk == 0).all()
+    ref = x0.double() + a.double() @ W2.double()
+    assert (outs[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(lay.unpack_planes(outs[0][1], M, D), outs[0][0] * gn)
+    want = (outs[0][0].double() ** 2).reshape(M, D // 16, 16).sum(-1).T
+    assert (outs[0][2][:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
+
+
 @pytest.mark.parametrize("M,K,F", [(2, 2048, 8192), (16, 256, 512), (33, 512, 1024)])
 def test_gemm_swiglu_emit(M, K, F):
     d = dev()
