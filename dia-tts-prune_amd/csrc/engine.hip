@@ -68,6 +68,11 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   const long xs = mt * xkt * 512, as = mt * akt * 512, hs = mt * hkt * 512;   // plane strides (elements)
   const int nqkv = (d.q_heads + 2 * d.kv_heads) * 128;
   int n = 0, rc;
+  // 17..32 rows: every GEMM may split K inside dia_gemm (k_gemm32 / k_gemm32m) when it is handed the scratch
+  const bool two_tiles = R > 16 && R <= 32 && d.sk_scratch && d.sk_tickets && d.sk_scratch_floats > 0;
+  auto lend_scratch = [&](dia_gemm_args& g) {
+    if (two_tiles) { g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets; g.sk_scratch_floats = d.sk_scratch_floats; }
+  };
 
   for (int l = 0; l < d.n_layer; ++l) {
     const dia_dec_layer& L = e->layers[l];
@@ -77,7 +82,8 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.W = L.w_qkv; g.KT = L.kt_qkv; g.nstrips = L.ns_qkv; g.epi = DIA_EPI_SCALE_STORE;
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
     g.out = d.qkv; g.ldo = nqkv; g.strip_map = L.smap_qkv;
-    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
+    lend_scratch(g);
+  if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     dia_attn_args a = {};
     a.mode = DIA_ATTN_SELF; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.kv_heads; a.group = d.q_heads / d.kv_heads;
@@ -94,7 +100,8 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.W = L.w_o; g.KT = L.kt_o; g.nstrips = L.ns_o; g.epi = DIA_EPI_RESID_EMIT;
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_ca; g.cmap = L.cmap_ca;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
-    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
+    lend_scratch(g);
+  if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // cross-attention query (layers.py:273, 278)
     g = {};
@@ -102,7 +109,8 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.W = L.w_cq; g.KT = L.kt_cq; g.nstrips = L.ns_cq; g.epi = DIA_EPI_SCALE_STORE;
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
     g.out = d.qc; g.ldo = d.cq_heads * 128; g.strip_map = L.smap_cq;
-    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
+    lend_scratch(g);
+  if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     a = {};
     a.mode = DIA_ATTN_CROSS; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.cq_heads; a.group = 1;
@@ -117,7 +125,8 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.W = L.w_co; g.KT = L.kt_co; g.nstrips = L.ns_co; g.epi = DIA_EPI_RESID_EMIT;
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_mlp; g.cmap = L.cmap_mlp;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
-    if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
+    lend_scratch(g);
+  if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // SwiGLU MLP (layers.py:95-104)
     dia_gemm_args gi = {};
@@ -137,7 +146,8 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     if (const char* ev = getenv("DIA_DBG_WO_SK")) wo_sk = atoi(ev) >= 1 && atoi(ev) <= 4 ? atoi(ev) : wo_sk;
     g.sk = wo_sk; g.sk_scratch = wo_sk > 1 ? d.sk_scratch : nullptr; g.sk_tickets = wo_sk > 1 ? d.sk_tickets : nullptr;
     if (R > 16 && R <= 32) {      // two m-tiles: dia_gemm splits K = 8192 four ways by itself (k_gemm32)
-      g.sk = 1; g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets; g.sk_scratch_floats = (int64_t)(d.D / 16) * 4 * 512;
+      g.sk = 1; g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets;
+      g.sk_scratch_floats = d.sk_scratch_floats > 0 ? d.sk_scratch_floats : (int64_t)(d.D / 16) * 4 * 512;
     }
     if (const char* ev = getenv("DIA_DBG_WO_NW")) g.nw = atoi(ev);
     if (const char* ev = getenv("DIA_DBG_WO_SPW")) g.spw = atoi(ev);
@@ -155,6 +165,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
       if (rc != DIA_E_ARG) return rc;
       e->mlp_fused = 0;                      // not available for this model: do not try again
     }
+    lend_scratch(gi);
     if ((rc = dia_gemm(&gi, st))) return rc; mark(e, n++);
     rc = dia_gemm(&g, st);
     if (rc == DIA_E_ARG && g.sk > 1) { g.sk = 1; g.sk_scratch = nullptr; g.sk_tickets = nullptr; rc = dia_gemm(&g, st); }
@@ -167,6 +178,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   g.W = d.w_logits; g.KT = d.kt_logits; g.nstrips = d.ns_logits; g.epi = DIA_EPI_SCALE_STORE;
   g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
   g.out = d.logits; g.ldo = d.ld_logits;
+  lend_scratch(g);
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
   if (with_sampler) {
     if ((rc = dia_sample(&d.sample, st))) return rc; mark(e, n++);

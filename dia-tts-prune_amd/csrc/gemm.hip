@@ -895,6 +895,128 @@ int launch_g32(const GemmK& k, int sk, hipStream_t st) {
   return dia_check_launch("k_gemm32");
 }
 
+// 17..32 rows, K = 2048-class shapes with many strips (qkv, wi, logits at batch 9-16): the persistent form of
+// k_gemm32.  A one-strip workgroup would re-read the whole 393 KB activation image per strip (measured: wi 47 us,
+// worse than the generic kernel's 38); here a workgroup keeps its K half of both m-tiles in registers (8 waves x
+// 4 k-tiles, 96 VGPRs) and walks strips blockIdx.x, +gridDim.x, ... with double-buffered weight tiles; the two
+// K halves of a strip (gridDim.y = 2) meet through the fence-free slab hand-off, strip by strip.
+__global__ __launch_bounds__(512) void k_gemm32m(GemmK p) {
+  constexpr int NW = 8, MT = 2, KPW = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                              // [NW][MT][64]
+  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * MT * 64);   // [MT][16][17]
+  float* inv_s = tile + MT * 16 * 17;                                           // [32]
+  __shared__ int sk_flag;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ks = blockIdx.y, SK = gridDim.y, G = gridDim.x;
+  const int kt0 = ks * (NW * KPW) + w * KPW;
+  const int e_mt = tid >> 5, e_r = (tid >> 1) & 15, half = tid & 1;
+  const int m = e_mt * 16 + e_r;
+  const bool e_thread = tid < 32 * MT;
+  const bool live = e_thread && m < p.M;
+  const bool resid = p.epi == DIA_EPI_RESID_EMIT;
+  float xpre[8], gpre[8];
+  bf16x8 a[MT][KPW][DIA_NPLANES];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = min(mt * 16 + (lane & 15), p.M - 1);
+    const long aoff = ((long)(row >> 4) * p.a_ktiles * 64 + ((lane & 48) | (row & 15))) * 8;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl)
+        a[mt][i][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff + (long)(kt0 + i) * 512);
+  }
+  {
+    const int s_row = tid >> 3, s_part = tid & 7;
+    float s0 = 0.f;
+    if (tid < 256 && p.ssq_in != nullptr && s_row < p.M)
+      for (int i = s_part; i < p.ssq_in_n; i += 8) s0 += p.ssq_in[(long)i * p.ssq_ld + s_row];
+    s0 += __shfl_xor(s0, 1, 64);
+    s0 += __shfl_xor(s0, 2, 64);
+    s0 += __shfl_xor(s0, 4, 64);
+    if (tid < 256 && s_part == 0) inv_s[s_row] = (p.ssq_in != nullptr) ? rsqrtf(s0 * p.inv_d + p.eps) : 1.0f;
+  }
+  const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + (long)kt0 * 64 + lane;
+  auto load_strip = [&](bf16x8 (&b)[KPW], int strip) {
+    const bf16x8* Wt = Wl + (long)strip * p.KT * 64;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) b[i] = DIA_WLOAD(Wt + (long)i * 64);
+  };
+  auto load_resid = [&](int strip) {
+    const int n0 = strip * 16 + half * 8;
+    const float* o = p.out + (long)(live ? m : 0) * p.ldo + n0;
+    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+    xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+    xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gpre[j] = p.gnext ? p.gnext[n0 + j] : 1.0f;
+  };
+  bf16x8 b0[KPW], b1[KPW];
+  if (resid && e_thread) load_resid(blockIdx.x);
+  __builtin_amdgcn_sched_barrier(0);
+  load_strip(b0, blockIdx.x);
+  __builtin_amdgcn_sched_barrier(0);
+  auto body = [&](bf16x8 (&bc)[KPW], bf16x8 (&bn)[KPW], int strip) {
+    const int next = strip + G;
+    if (next < p.nstrips) load_strip(bn, next);
+    f32x4 acc[MT] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][i][pl], bc[i], acc[mt], 0, 0, 0);
+    reduce_to_tile<MT, NW, true>(acc, red, tile, tid, lane, w);
+    bool last_slice = true;
+    if (SK > 1) {
+      float* slab = p.sk_scratch + ((long)strip * SK + ks) * (MT * 256);
+      if (tid < MT * 128) {
+        const int t = tid >> 7, e = (tid & 127) * 2;
+        st2_agent(slab + t * 256 + e, tile[(t * 16 + (e >> 4)) * 17 + (e & 15)], tile[(t * 16 + (e >> 4)) * 17 + (e & 15) + 1]);
+      }
+      // only the slab stores need their acknowledgement here; the weight tiles of the next strip, requested
+      // before them, are older and complete first (in-order), so this costs the store latency only
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+      if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(p.sk_tickets + strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == SK - 1;
+        if (last) __hip_atomic_store(p.sk_tickets + strip, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sk_flag = last;
+      }
+      __syncthreads();
+      last_slice = sk_flag != 0;
+      if (last_slice) {
+        if (tid < MT * 128) {
+          const int t = tid >> 7, e = (tid & 127) * 2;
+          const float* base = p.sk_scratch + (long)strip * SK * (MT * 256) + t * 256 + e;
+          float x0 = 0.f, x1 = 0.f;
+          for (int k = 0; k < SK; ++k) { const float2 v = ld2_agent(base + (long)k * (MT * 256)); x0 += v.x; x1 += v.y; }
+          tile[(t * 16 + (e >> 4)) * 17 + (e & 15)] = x0; tile[(t * 16 + (e >> 4)) * 17 + (e & 15) + 1] = x1;
+        }
+        __syncthreads();
+      }
+    }
+    if (e_thread) {
+      if (last_slice) run_epilogue(p, tile + (e_mt * 16 + e_r) * 17, inv_s[e_mt * 16 + e_r], m, strip * 16 + half * 8, half, strip, live, xpre, gpre);
+      if (next < p.nstrips && resid) load_resid(next);
+    }
+  };
+  for (int strip = blockIdx.x; strip < p.nstrips; strip += 2 * G) {
+    body(b0, b1, strip);
+    if (strip + G < p.nstrips) body(b1, b0, strip + G);
+  }
+}
+
+int launch_g32m(const GemmK& k, int sk, hipStream_t st) {
+  const size_t smem = sizeof(f32x4) * 8 * 2 * 64 + sizeof(float) * (2 * 16 * 17 + 32);
+  const int gx = k.nstrips < 128 ? k.nstrips : 128;
+  launch_kernel(k_gemm32m, dim3(gx, sk), dim3(512), smem, st, k);
+  return dia_check_launch("k_gemm32m");
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Prefill GEMM (encoder layers, cross-K/V projections: M = text bytes, tens to thousands of rows).
 // Here the contraction is dense and MFMA is the roofline, not HBM: a workgroup owns a 64-row x 256-column
@@ -1497,6 +1619,13 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
     // whole 393 KB activation image and loses to the generic kernel (wi 47 vs 38 us), so that case needs
     // DIA_DBG_G32_ALL to be selected
     if (sk32 == 1 && getenv("DIA_DBG_G32_ALL")) return launch_g32<8>(k, 1, st);
+    // K = 2048 with many strips: the persistent two-half form (k_gemm32m) is NOT selected by default — measured at
+    // batch 16: wi 36.4 us (generic 37.3), logits 25.8 (30.0), o 10.9 (12.4) but qkv 17.0 (12.6), cq 14.0 (11.9), and
+    // the step as a whole slower (7 302 vs 7 597 frames/s): a split-K hand-off per strip inside the persistent loop
+    // is a 3-4 us dependent chain that the next strip cannot hide.  DIA_DBG_G32M=1 selects it.
+    if (sk32 == 1 && a->KT == 64 && a->nstrips >= 128 && a->sk_scratch && a->sk_tickets && a->sk_scratch_floats >= (int64_t)a->nstrips * 2 * 512 &&
+        getenv("DIA_DBG_G32M"))
+      return launch_g32m(k, 2, st);
     if (sk32 > 1 && a->sk_scratch && a->sk_tickets && a->sk_scratch_floats >= (int64_t)a->nstrips * sk32 * 512) return launch_g32<8>(k, sk32, st);
   }
   if (sk > 1) return dia_fail(DIA_E_ARG, "dia_gemm: no split-K kernel for this shape");

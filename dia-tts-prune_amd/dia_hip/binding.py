@@ -132,7 +132,7 @@ class EngineDesc(C.Structure):
         ("ssq", C.c_void_p), ("qkv", C.c_void_p), ("qc", C.c_void_p), ("logits", C.c_void_p),
         ("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("text_len", C.c_void_p),
         ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p),
-        ("attn_scratch", C.c_void_p), ("attn_tickets", C.c_void_p), ("mlp_barrier", C.c_void_p),
+        ("attn_scratch", C.c_void_p), ("attn_tickets", C.c_void_p), ("sk_scratch_floats", C.c_int64), ("mlp_barrier", C.c_void_p),
         ("sample", SampleArgs),
     ]
 

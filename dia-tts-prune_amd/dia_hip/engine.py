@@ -267,8 +267,11 @@ class DecodeSession:
                   hb.lib().dia_attn_scratch_floats(B, d.cross_query_heads, self.S))
         self.attn_scratch = z(max(nsc, 1))
         self.attn_tickets = z(max(self.R * d.kv_heads, B * d.cross_query_heads), dt=torch.int32)
-        self.sk_scratch = z((self.D // 16) * 4 * 512)      # split-K slabs: up to 4 splits of one (<= 16 rows) or two m-tiles
-        self.sk_tickets = z(self.D // 16, dt=torch.int32)
+        # split-K slabs: up to 4 splits of wo (one or two m-tiles); with 17..32 rows every GEMM splits K in two
+        ns_max = max([self.D // 16, w.logits.ns] + [DL[k].ns for DL in w.dec_layers for k in ("qkv", "o", "cq", "co", "wi", "wo")])
+        n_scr = max((self.D // 16) * 4 * 512, ns_max * 2 * 512 if 16 < self.R <= 32 else 0)
+        self.sk_scratch = z(n_scr)
+        self.sk_tickets = z(ns_max, dt=torch.int32)
         self.mlp_barrier = z(2, dt=torch.int32)          # dia_mlp_fused: arrivals, error flag
 
         # token buffer + state machine (state.py:178-208; model.py:736-741)
@@ -388,6 +391,7 @@ class DecodeSession:
         ed.cos_t, ed.sin_t, ed.text_len = hb.ptr(w.cos_t), hb.ptr(w.sin_t), hb.ptr(self.text_len)
         ed.attn_scratch, ed.attn_tickets = hb.ptr(self.attn_scratch), hb.ptr(self.attn_tickets)
         ed.sk_scratch, ed.sk_tickets = hb.ptr(self.sk_scratch), hb.ptr(self.sk_tickets)
+        ed.sk_scratch_floats = self.sk_scratch.numel()
         ed.mlp_barrier = hb.ptr(self.mlp_barrier)
         ed.sample = self._sample_args()
         self._desc = ed

@@ -158,6 +158,50 @@ def test_gemm_two_mtiles(M, monkeypatch):
     f = torch.einsum("mk,kgf->mgf", h, wi.double())
     ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
     assert (lay.unpack_planes(P, M, F).double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # persistent two-half form (k_gemm32m): K = 2048, >= 128 strips, scratch lent -> SWIGLU again + RESID_EMIT
+    monkeypatch.delenv("DIA_DBG_G32_ALL")
+    monkeypatch.setenv("DIA_DBG_G32M", "1")
+    F2 = 2048
+    wi2 = bf16r(torch.randn(K, 2, F2, device=d) * 0.05)
+    Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi2))
+    A = lay.pack_planes(x * gw)
+    scr = torch.zeros(ns * 2 * 512, device=d); tk = torch.zeros(ns, dtype=torch.int32, device=d)
+    ss = strip_ssq(x, 32)
+    for _ in range(2):
+        P = torch.zeros(3, 2, F2 // 32, 64, 8, dtype=torch.bfloat16, device=d)
+        g = hb.GemmArgs()
+        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+        g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_SWIGLU_EMIT
+        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, 32
+        g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), F2 // 32
+        g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = hb.ptr(scr), hb.ptr(tk), scr.numel()
+        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+    torch.cuda.synchronize()
+    assert (tk == 0).all()
+    f = torch.einsum("mk,kgf->mgf", h, wi2.double())
+    ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
+    assert (lay.unpack_planes(P, M, F2).double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    Dn = 2048
+    Wn = bf16r(torch.randn(K, Dn, device=d) * 0.03)
+    xn0 = torch.randn(M, Dn, device=d); gnn = bf16r(1.0 + 0.1 * torch.randn(Dn, device=d))
+    Wt, kt, ns = lay.tile_weight(Wn)
+    An = lay.pack_planes(x)
+    xr = xn0.clone()
+    Pn = torch.zeros(3, 2, Dn // 32, 64, 8, dtype=torch.bfloat16, device=d); ssqn = torch.zeros(ns, 32, device=d)
+    scr = torch.zeros(ns * 2 * 512, device=d); tk = torch.zeros(ns, dtype=torch.int32, device=d)
+    g = hb.GemmArgs()
+    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(An), An[0].numel(), An.shape[2], M
+    g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_RESID_EMIT
+    g.ssq_ld, g.out, g.ldo, g.gnext = 32, hb.ptr(xr), Dn, hb.ptr(gnn)
+    g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(Pn), Pn[0].numel(), Dn // 32, hb.ptr(ssqn)
+    g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = hb.ptr(scr), hb.ptr(tk), scr.numel()
+    hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+    torch.cuda.synchronize()
+    refn = xn0.double() + x.double() @ Wn.double()
+    assert (xr.double() - refn).abs().max().item() <= 2e-5 * refn.abs().max().item()
+    assert torch.equal(lay.unpack_planes(Pn, M, Dn), xr * gnn)
+    want = (xr.double() ** 2).reshape(M, Dn // 16, 16).sum(-1).T
+    assert (ssqn[:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
     # RESID_EMIT, K = 8192: split-K 4 inside dia_gemm, twice for reproducibility
     K2, D = 8192, 256
     a = torch.randn(M, K2, device=d)
