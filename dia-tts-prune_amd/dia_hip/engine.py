@@ -307,15 +307,24 @@ class DecodeSession:
         self.delay = torch.tensor(list(da.delay_pattern), dtype=torch.int32, device=dev)
 
         # Exp(1) variates for the multinomial draw: the reference's generator stream after
-        # torch.manual_seed(seed) (model.py:679-683), one [C,V] draw per step, drawn in one batch
+        # torch.manual_seed(seed) (model.py:679-683), one [C,V] draw per sampled step.  Drawing 3071 rows takes
+        # 0.7 s per utterance on the host, so they are drawn in chunks as the decode advances (the stream of a
+        # generator is the same whether it is consumed in one draw or in pieces) and uploaded ahead of the steps
+        # that read them; a generation that ends early never draws the rest.
         self.noise_steps = self.max_tokens - 1
+        self._noise_rows = 0                    # rows [0, _noise_rows) are on the device
+        self._issued = 0                        # decode steps enqueued so far
+        self._gens = None
         if temperature != 0.0:
             if noise is not None:
                 nz = noise.to(torch.float32)
                 if tuple(nz.shape) != (B, self.noise_steps, self.C, self.V):
                     raise ValueError(f"noise must be [B,{self.noise_steps},{self.C},{self.V}]")
+                self.noise = nz.to(dev)
+                self._noise_rows = self.noise_steps
             else:
-                nz = torch.empty(B, self.noise_steps, self.C, self.V, dtype=torch.float32)
+                self.noise = torch.empty(B, self.noise_steps, self.C, self.V, dtype=torch.float32, device=dev)
+                self._gens = []
                 for b in range(B):
                     g = torch.Generator()
                     sd = None if seeds is None else seeds[b]
@@ -323,10 +332,10 @@ class DecodeSession:
                         g.seed()
                     else:
                         g.manual_seed(int(sd))
-                    nz[b].exponential_(1.0, generator=g)
-            self.noise = nz.to(dev)
+                    self._gens.append(g)
         else:
             self.noise = None
+            self._noise_rows = self.noise_steps
 
         self.sample_params = dict(cfg_scale=float(cfg_scale), temperature=float(temperature), top_p=float(top_p),
                                   top_k=int(top_k or 0))
@@ -618,10 +627,36 @@ class DecodeSession:
         self.cur.copy_(torch.tensor(cur, dtype=torch.int32))
 
     # ------------------------------------------------------------------ decode
+    def ensure_noise(self, rows: int):
+        """Make the Exp(1) rows [0, rows) resident (no-op for explicit noise / greedy sampling).  Step number s of
+        an utterance reads row s - first_step, so `rows` = decode steps enqueued so far is always enough."""
+        rows = min(int(rows), self.noise_steps)
+        if self._gens is None or rows <= self._noise_rows:
+            return
+        r0, n = self._noise_rows, rows - self._noise_rows
+
+        def draw(b):
+            t = torch.empty(n, self.C, self.V, dtype=torch.float32)
+            t.exponential_(1.0, generator=self._gens[b])
+            return t
+
+        if self.B > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(self.B, 8)) as pool:      # torch releases the GIL while it draws
+                parts = list(pool.map(draw, range(self.B)))
+        else:
+            parts = [draw(0)]
+        host = torch.stack(parts)
+        with torch.cuda.stream(self.stream):
+            self.noise[:, r0:rows].copy_(host, non_blocking=False)
+        self._noise_rows = rows
+
     def decode(self, n_steps: int, use_graph: bool = True):
         if not self.prefilled:
             raise hb.DiaHipError("decode() before prefill()")
+        self.ensure_noise(self._issued + int(n_steps))
         hb.check(hb.lib().dia_engine_decode(self._engine, int(n_steps), int(bool(use_graph))), "dia_engine_decode")
+        self._issued += int(n_steps)
 
     def set_prefetch(self, lookahead: int):
         hb.check(hb.lib().dia_engine_set_prefetch(self._engine, int(lookahead)), "dia_engine_set_prefetch")
@@ -633,7 +668,9 @@ class DecodeSession:
         """per-launch milliseconds of one eager decode step (HIP events on the engine's stream)."""
         n = hb.lib().dia_engine_launches_per_step(self._engine)
         buf = (C.c_float * n)()
+        self.ensure_noise(self._issued + 1)
         hb.check(hb.lib().dia_engine_profile_step(self._engine, buf, n), "dia_engine_profile_step")
+        self._issued += 1
         return np.array(buf[:], dtype=np.float64)
 
     def time_wi_launches(self, reps: int = 5) -> float:
@@ -715,6 +752,7 @@ class DecodeSession:
             n = min(poll, remaining)
             self.decode(n, use_graph)
             remaining -= n
+            self.ensure_noise(self._issued + min(poll, remaining))      # next chunk's noise is drawn while this one runs
             self.sync()
             if bool((self.fsm[:, 3] != 0).all().item()):
                 break
