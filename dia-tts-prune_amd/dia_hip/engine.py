@@ -744,7 +744,7 @@ class DecodeSession:
     def steps_total(self) -> int:
         return self.max_tokens - self.prefill_step
 
-    def run(self, use_graph: bool = True, poll: int = 128):
+    def run(self, use_graph: bool = True, poll: int = 64):
         """Run until every utterance has finished (EOS countdown or max_tokens); the host looks at
         the device-side `done` flags every `poll` steps only."""
         remaining = self.steps_total()
