@@ -748,8 +748,10 @@ class DecodeSession:
         """Run until every utterance has finished (EOS countdown or max_tokens); the host looks at
         the device-side `done` flags every `poll` steps only."""
         remaining = self.steps_total()
+        first = True
         while remaining > 0:
-            n = min(poll, remaining)
+            n = min(8 if first else poll, remaining)        # a short first chunk: its noise rows are the only ones drawn
+            first = False                                   # before anything runs (0.23 ms of host time per row)
             self.decode(n, use_graph)
             remaining -= n
             self.ensure_noise(self._issued + min(poll, remaining))      # next chunk's noise is drawn while this one runs
