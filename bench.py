@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU")
     ap.add_argument("--kv", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--cpu-steps", type=int, default=12, help="decode steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=40, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--prefetch", type=int, default=0, help="weight prefetch lookahead in launches (experiment)")
