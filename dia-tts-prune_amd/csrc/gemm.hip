@@ -47,6 +47,8 @@ void launch_kernel(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream_t st
   else hipLaunchKernelGGL(kern, grid, block, smem, st, arg);
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // plain vector: HIP's uint4 struct defeats SROA in register arrays
+
 struct GemmK {
   const bf16_raw* A; long a_plane_stride; int a_ktiles; int M;
   const bf16_raw* W; int KT; int nstrips; int epi;
@@ -62,6 +64,7 @@ struct GemmK {
   float* sk_scratch; int* sk_tickets;     // cross-workgroup split-K (gridDim.y > 1)
   int kv_vblocked;
   const int* row_b; const int* seg_off;   // CROSSKV over a packed batch
+  const unsigned char* sp_blocks; const unsigned int* sp_toff;   // zero-skipping weight stream (k_gemv_sparse)
 };
 
 __device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v) {
@@ -690,6 +693,165 @@ constexpr size_t mlp_smem(int kt1, int kt2) {
   return sizeof(f32x4) * 16 * 64 + sizeof(float) * (16 * 17 + 16) + (size_t)DIA_NPLANES * (kt1 > kt2 ? kt1 : kt2) * 4 * 2 * 16;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// M <= 4 GEMV over the ZERO-SKIPPING weight stream of an unstructured-pruned matrix (layout.sparse_tile_weight:
+// per tile 64 lane masks + 4 row prefixes + the non-zero bf16 values, at most 1024 bytes; denser tiles raw).
+// The persistent multi-strip form of k_gemv_small with a different B producer: one 16-byte load per lane still
+// fetches a whole tile (lanes past the block re-read its last chunk — same cache line, no traffic), the loaded
+// chunks are prefetched one strip ahead exactly like dense tiles, and each wave expands them through its own LDS
+// scratch (write the chunks, read mask byte + row prefix, 4-step DPP scan for the lane's offset, eight 2-byte
+// reads) into the MFMA B fragment.  The arithmetic and its order are those of the dense kernel: results are
+// bit-identical to dia_gemm on the same (zero-holding) matrix, the stream is 0.59x the bytes at 50 % zeros.
+// MEASURED (wi_fused 2048 x 16384, M = 2): 22.6 us at 50 % zeros, 21.8 us at 70 %, against 15.7 us for the dense
+// stream — the expansion, not the bytes, is the limit: eight 2-byte LDS gathers per lane and tile (bank-conflicted,
+// 2 300 LDS instructions per workgroup) cost more than the 28-41 MB they save at 4.4 TB/s.  Kept as a tested
+// kernel-level experiment for SURVEY.md §8(f)-4; the engine streams unstructured-pruned checkpoints dense.
+template <int KPW, int RS, int MAXS>
+__global__ __launch_bounds__(1024) void k_gemv_sparse(GemmK p) {
+  constexpr int NW = 16, KT = NW * KPW, NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][64]
+  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * 64);   // [16][17]
+  float* inv_s = tile + 16 * 17;                                           // [16]
+  bf16x8* As = reinterpret_cast<bf16x8*>(smem_raw + sizeof(f32x4) * NW * 64 + sizeof(float) * (16 * 17 + 16));
+  unsigned char* dec = reinterpret_cast<unsigned char*>(As) + (size_t)DIA_NPLANES * KT * 4 * RS * 16;   // [NW][KPW][1024]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kt0 = w * KPW;
+  const int G = gridDim.x;
+  const int e_r = (tid >> 1) & 15, half = tid & 1, m = e_r;
+  const bool e_thread = tid < 32;
+  const bool live = e_thread && m < p.M;
+  float xpre[8], gpre[8];
+
+  // tile offsets of every strip this workgroup walks (a handful of words: no dependent load in the loop)
+  unsigned int toff[MAXS][KPW];
+#pragma unroll
+  for (int sI = 0; sI < MAXS; ++sI) {
+    const int strip = min(blockIdx.x + sI * G, p.nstrips - 1);
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) toff[sI][i] = p.sp_toff[(long)strip * KT + kt0 + i];
+  }
+  // A image, row scales, residual operands: as k_gemv_small
+  constexpr int CH = (3 * KPW * RS + 15) / 16;
+  constexpr int nchunks = DIA_NPLANES * KT * 4 * RS;
+  bf16x8 v0[CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    const int c = min(tid + u * NT, nchunks - 1);
+    const int row = c % RS, kq = (c / RS) & 3, kt = (c / (4 * RS)) % KT, pl = c / (4 * RS * KT);
+    v0[u] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)kt * 64 + row + 16 * kq) * 8);
+  }
+  const bool has_norm = p.ssq_in != nullptr;
+  const int s_row = tid >> 3, s_part = tid & 7;
+  float s0 = 0.f;
+  if (tid < 128 && has_norm && s_row < p.M)
+    for (int i = s_part; i < p.ssq_in_n; i += 8) s0 += p.ssq_in[(long)i * p.ssq_ld + s_row];
+  const bool resid = p.epi == DIA_EPI_RESID_EMIT;
+  auto load_resid = [&](int strip) {
+    const int n0 = strip * 16 + half * 8;
+    const float* o = p.out + (long)(live ? m : 0) * p.ldo + n0;
+    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+    xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+    xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+    const float4 ga = *reinterpret_cast<const float4*>(p.gnext + n0), gb = *reinterpret_cast<const float4*>(p.gnext + n0 + 4);
+    gpre[0] = ga.x; gpre[1] = ga.y; gpre[2] = ga.z; gpre[3] = ga.w;
+    gpre[4] = gb.x; gpre[5] = gb.y; gpre[6] = gb.z; gpre[7] = gb.w;
+  };
+  if (resid && e_thread) load_resid(blockIdx.x);
+  auto load_blocks = [&](u32x4 (&b)[KPW], const unsigned int (&t)[KPW]) {
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+      const unsigned int nch = t[i] & 255u;
+      const int l = min(lane, (int)(nch ? nch : 64u) - 1);
+      b[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.sp_blocks) + (long)(t[i] >> 8) + l);
+    }
+  };
+  u32x4 b0[KPW], b1[KPW];
+  load_blocks(b0, toff[0]);
+#pragma unroll
+  for (int u = 0; u < CH; ++u)
+    if (tid + u * NT < nchunks) As[tid + u * NT] = v0[u];
+  s0 += __shfl_xor(s0, 1, 64);
+  s0 += __shfl_xor(s0, 2, 64);
+  s0 += __shfl_xor(s0, 4, 64);
+  if (tid < 128 && s_part == 0) inv_s[s_row] = has_norm ? rsqrtf(s0 * p.inv_d + p.eps) : 1.0f;
+  lds_barrier();
+
+  const int arow = min(lane & 15, RS - 1), akq = lane >> 4;
+  unsigned char* dw = dec + (size_t)w * KPW * 1024;
+  auto body = [&](u32x4 (&bc)[KPW], u32x4 (&bn)[KPW], const unsigned int (&tc)[KPW], const unsigned int (&tn)[KPW], int strip) {
+    const int next = strip + G;
+    if (next < p.nstrips) load_blocks(bn, tn);
+    // expand this strip's tiles: chunks -> this wave's LDS scratch -> fragments
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) *reinterpret_cast<u32x4*>(dw + i * 1024 + lane * 16) = bc[i];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+      bf16x8 bfrag;
+      if ((tc[i] & 255u) == 0u) {                       // raw tile (wave-uniform)
+        bfrag = __builtin_bit_cast(bf16x8, bc[i]);
+      } else {
+        const unsigned char* blk = dw + i * 1024;
+        const unsigned int mk = blk[lane];
+        const int cnt = __popc(mk);
+        int incl = cnt;                                 // inclusive scan over the 16-lane row
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
+        const int base = reinterpret_cast<const unsigned short*>(blk + 64)[lane >> 4] + incl - cnt;
+        const unsigned short* vals = reinterpret_cast<const unsigned short*>(blk + 80);
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int rk = __popc(mk & ((1u << j) - 1u));
+          const unsigned short v = vals[min(base + rk, 471)];
+          e[j] = ((mk >> j) & 1u) ? v : (unsigned short)0;
+        }
+        u32x4 packed;
+        packed[0] = e[0] | ((unsigned int)e[1] << 16); packed[1] = e[2] | ((unsigned int)e[3] << 16);
+        packed[2] = e[4] | ((unsigned int)e[5] << 16); packed[3] = e[6] | ((unsigned int)e[7] << 16);
+        bfrag = __builtin_bit_cast(bf16x8, packed);
+      }
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+        const bf16x8 a = As[((pl * KT + kt0 + i) * 4 + akq) * RS + arow];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag, acc[0], 0, 0, 0);
+      }
+    }
+    reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
+    if (e_thread) {
+      const int n0 = strip * 16 + half * 8;
+      run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
+      if (next < p.nstrips && resid) load_resid(next);
+    }
+  };
+#pragma unroll
+  for (int sI = 0; sI < MAXS; sI += 2) {
+    const int strip = blockIdx.x + sI * G;
+    if (strip < p.nstrips) body(b0, b1, toff[sI], toff[sI + 1 < MAXS ? sI + 1 : sI], strip);
+    if (strip + G < p.nstrips && sI + 1 < MAXS) body(b1, b0, toff[sI + 1], toff[sI + 2 < MAXS ? sI + 2 : sI + 1], strip + G);
+  }
+}
+
+template <int KPW, int RS>
+int launch_sparse(const GemmK& k, hipStream_t st) {
+  constexpr int MAXS = 8;
+  const size_t smem = sizeof(f32x4) * 16 * 64 + sizeof(float) * (16 * 17 + 16) + (size_t)DIA_NPLANES * (16 * KPW) * 4 * RS * 16 + (size_t)16 * KPW * 1024;
+  int rc = dia_kernels_init_once();
+  if (rc) return rc;
+  int grid = (k.nstrips + MAXS - 1) / MAXS;
+  if (grid < 256 && k.nstrips >= 256) grid = 256;
+  if (grid > k.nstrips) grid = k.nstrips;
+  if ((k.nstrips + grid - 1) / grid > MAXS) return dia_fail(DIA_E_ARG, "dia_gemm: too many strips for the sparse kernel");
+  launch_kernel(k_gemv_sparse<KPW, RS, MAXS>, dim3(grid), dim3(1024), smem, st, k);
+  return dia_check_launch("k_gemv_sparse");
+}
+
 // 5..16 rows (batch 3-8): one m-tile, A fragments held in registers for the workgroup's whole life
 // (each wave owns a fixed K range of KPW k-tiles = 12*KPW VGPRs) and reused for every strip the
 // workgroup walks; weight tiles double-buffered across strips like k_gemv_small.
@@ -1029,7 +1191,6 @@ int launch_g32m(const GemmK& k, int sk, hipStream_t st) {
 // straight from global memory into the B operand registers, PD chunks ahead; the two wave rows and the row
 // groups of the same column block re-read them from L2.  fp32-exact like every other GEMM here: 3 planes
 // x bf16 weights.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // plain vector: HIP's uint4 struct defeats SROA in register arrays
 constexpr int GT_MT = 4, GT_WM = 2, GT_WS = 4;   // workgroup: 4 m-tiles; per wave: 2 m-tiles x 4 strips
 constexpr size_t gt_abuf(int kc) { return (size_t)kc * DIA_NPLANES * GT_MT * 64 * 16; }    // bytes of one staged chunk (24 KiB at 2 k-tiles)
 constexpr size_t gt_smem(int kc, int nw) { return 2 * gt_abuf(kc) + sizeof(float) * (nw * 2 * 16 * 17 + 64); }
@@ -1530,12 +1691,20 @@ static int fill_gemmk(const dia_gemm_args* a, GemmK& k) {
   k.cmap = a->cmap; k.strip_map = a->strip_map;
   k.sk_scratch = a->sk_scratch; k.sk_tickets = a->sk_tickets; k.kv_vblocked = a->kv_vblocked;
   k.row_b = a->row_b; k.seg_off = a->seg_off;
+  k.sp_blocks = (const unsigned char*)a->sp_blocks; k.sp_toff = (const unsigned int*)a->sp_toff;
   return DIA_OK;
 }
 
 // large-LDS attribute of every small-M instantiation, set once outside any graph capture
+template <int KPW, int RS>
+static int sparse_attr() {
+  const size_t smem = sizeof(f32x4) * 16 * 64 + sizeof(float) * (16 * 17 + 16) + (size_t)DIA_NPLANES * (16 * KPW) * 4 * RS * 16 + (size_t)16 * KPW * 1024;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_sparse<KPW, RS, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess;
+}
+
 int dia_gemm_init() {
   int rc = 0;
+  rc |= sparse_attr<4, 2>(); rc |= sparse_attr<4, 4>(); rc |= sparse_attr<2, 2>(); rc |= sparse_attr<2, 4>(); rc |= sparse_attr<1, 2>(); rc |= sparse_attr<1, 4>();
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fused<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_smem(64, 128)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fused<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_smem(16, 16)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile_ws<2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
@@ -1551,7 +1720,7 @@ int dia_gemm_init() {
 }
 
 extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
-  if (!a || !a->A || !a->W) return dia_fail(DIA_E_ARG, "dia_gemm: null argument");
+  if (!a || !a->A || (!a->W && !a->sp_blocks)) return dia_fail(DIA_E_ARG, "dia_gemm: null argument");
   if (a->M <= 0 || a->KT <= 0 || a->nstrips <= 0) return dia_fail(DIA_E_ARG, "dia_gemm: empty problem");
   if (a->KT > a->a_ktiles) return dia_fail(DIA_E_ARG, "dia_gemm: weight K exceeds the plane layout's K");
   if (a->a_plane_stride % 8 != 0 || a->p_plane_stride % 8 != 0) return dia_fail(DIA_E_ARG, "dia_gemm: plane stride must be a multiple of 8");
@@ -1569,6 +1738,16 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   GemmK k;
   fill_gemmk(a, k);
 
+  if (a->sp_blocks || a->sp_toff) {       // zero-skipping stream: M <= 4, K = 16 * {1, 2, 4} k-tiles, no split-K
+    if (!a->sp_blocks || !a->sp_toff || a->M > 4 || a->epi == DIA_EPI_CROSSKV || (a->epi == DIA_EPI_RESID_EMIT && !a->gnext) || a->sk > 1)
+      return dia_fail(DIA_E_ARG, "dia_gemm: the sparse stream serves M <= 4 without split-K");
+    const int rs = a->M <= 2 ? 2 : 4;
+    hipStream_t st0 = (hipStream_t)stream;
+    if (a->KT == 64) return rs == 2 ? launch_sparse<4, 2>(k, st0) : launch_sparse<4, 4>(k, st0);
+    if (a->KT == 32) return rs == 2 ? launch_sparse<2, 2>(k, st0) : launch_sparse<2, 4>(k, st0);
+    if (a->KT == 16) return rs == 2 ? launch_sparse<1, 2>(k, st0) : launch_sparse<1, 4>(k, st0);
+    return dia_fail(DIA_E_ARG, "dia_gemm: no sparse kernel for this K");
+  }
   int nw = a->nw;
   if (nw == 0) {
     // many strips -> few fat waves (deep load queues); few strips -> many waves per strip.

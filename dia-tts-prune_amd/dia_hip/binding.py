@@ -43,6 +43,7 @@ class GemmArgs(C.Structure):
         ("cmap", C.c_void_p), ("strip_map", C.c_void_p),
         ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p), ("sk", C.c_int32), ("kv_vblocked", C.c_int32),
         ("row_b", C.c_void_p), ("seg_off", C.c_void_p), ("sk_scratch_floats", C.c_int64),
+        ("sp_blocks", C.c_void_p), ("sp_toff", C.c_void_p),
     ]
 
 

@@ -106,3 +106,81 @@ def v_to_blocked(v: torch.Tensor) -> torch.Tensor:
 def v_from_blocked(vb: torch.Tensor) -> torch.Tensor:
     *lead, nb, H, k = vb.shape
     return vb.transpose(-1, -2).reshape(*lead, nb * k, H).contiguous()
+
+
+SPARSE_HEADER = 80          # bytes: 64 lane masks + 4 x uint16 row prefixes + 8 pad
+
+
+def sparse_tile_weight(tiles: torch.Tensor):
+    """bf16 weight tiles [ns, kt, 64, 8] -> (blocks uint8 [bytes], toff int32 [ns*kt]) — the zero-skipping stream
+    format for unstructured-pruned matrices (offline_prune.py --prune-mode unstructured):
+
+      block of a tile = [64 x uint8 lane masks (bit j = element j of the lane's 8-element fragment is non-zero)]
+                        [4 x uint16: non-zeros in lanes < 16*q]  [8 pad bytes]
+                        [non-zero bf16 values, lane-major]                 padded to 16 bytes, <= 1024 bytes
+      a tile with more than 472 non-zeros is stored raw (1024 bytes, the dense fragment order)
+      toff[tile] = (block offset / 16) << 8 | (block size / 16, or 0 for a raw tile)
+
+    One 16-byte load per lane still fetches a whole tile (lanes past the block re-read its last chunk), so the
+    kernel keeps the dense kernel's prefetch structure and simply moves fewer bytes."""
+    ns, kt = tiles.shape[0], tiles.shape[1]
+    dev = tiles.device
+    raw = tiles.contiguous().view(torch.int16).reshape(ns * kt, 64, 8)
+    nzm = raw != 0                                                    # [T, 64, 8]
+    cnt = nzm.sum(dim=2)                                              # [T, 64]
+    nnz = cnt.sum(dim=1)                                              # [T]
+    dense = nnz > 472
+    size = torch.where(dense, torch.full_like(nnz, 1024), (SPARSE_HEADER + 2 * nnz + 15) // 16 * 16)
+    off = torch.cumsum(size, 0) - size
+    total = int(size.sum().item())
+    blocks = torch.zeros(total, dtype=torch.uint8, device=dev)
+    T = ns * kt
+    # raw tiles
+    if bool(dense.any()):
+        idx = torch.nonzero(dense).flatten()
+        dst = (off[idx][:, None] + torch.arange(1024, device=dev)[None, :]).reshape(-1)
+        blocks[dst] = raw[idx].reshape(len(idx), -1).view(torch.uint8).reshape(-1)
+    sp = ~dense
+    if bool(sp.any()):
+        idx = torch.nonzero(sp).flatten()
+        bits = (nzm[idx].to(torch.int32) * (1 << torch.arange(8, device=dev, dtype=torch.int32))[None, None, :]).sum(dim=2)   # [S, 64]
+        dst = (off[idx][:, None] + torch.arange(64, device=dev)[None, :]).reshape(-1)
+        blocks[dst] = bits.to(torch.uint8).reshape(-1)
+        rowpre = torch.cumsum(cnt[idx].reshape(len(idx), 4, 16).sum(dim=2), dim=1) - cnt[idx].reshape(len(idx), 4, 16).sum(dim=2)   # [S, 4]
+        rp = rowpre.to(torch.int16).contiguous().view(torch.uint8).reshape(len(idx), 8)
+        dst = (off[idx][:, None] + 64 + torch.arange(8, device=dev)[None, :]).reshape(-1)
+        blocks[dst] = rp.reshape(-1)
+        # values: global order of the non-zeros is already (tile, lane, j)
+        sel = nzm[idx]
+        vals = raw[idx][sel]                                           # int16 [sum nnz]
+        tile_of = torch.repeat_interleave(torch.arange(len(idx), device=dev), nnz[idx])
+        start = torch.cumsum(nnz[idx], 0) - nnz[idx]
+        within = torch.arange(vals.numel(), device=dev) - start[tile_of]
+        dstb = off[idx][tile_of] + SPARSE_HEADER + 2 * within
+        vb = vals.contiguous().view(torch.uint8).reshape(-1, 2)
+        blocks[dstb] = vb[:, 0]
+        blocks[dstb + 1] = vb[:, 1]
+    chunks = torch.where(dense, torch.zeros_like(size), size // 16)
+    toff = ((off // 16) << 8 | chunks).to(torch.int32)
+    return blocks, toff.contiguous()
+
+
+def sparse_untile(blocks: torch.Tensor, toff: torch.Tensor, ns: int, kt: int) -> torch.Tensor:
+    """inverse of sparse_tile_weight (test helper, slow): bf16 tiles [ns, kt, 64, 8]"""
+    b = blocks.cpu().numpy()
+    t = toff.cpu().numpy().astype("int64") & 0xFFFFFFFF
+    import numpy as np
+    out = np.zeros((ns * kt, 64, 8), dtype=np.int16)
+    for i in range(ns * kt):
+        o, ch = int(t[i] >> 8) * 16, int(t[i] & 255)
+        if ch == 0:
+            out[i] = b[o: o + 1024].view(np.int16).reshape(64, 8)
+            continue
+        masks = b[o: o + 64]
+        vals = b[o + SPARSE_HEADER: o + ch * 16].view(np.int16)
+        k = 0
+        for l in range(64):
+            for j in range(8):
+                if masks[l] >> j & 1:
+                    out[i, l, j] = vals[k]; k += 1
+    return torch.from_numpy(out).view(torch.bfloat16).reshape(ns, kt, 64, 8)

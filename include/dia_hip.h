@@ -109,6 +109,11 @@ typedef struct {
   /* capacity of sk_scratch in floats (0 = not stated: only the explicit `sk` split-K, nstrips * sk * 256 floats, is
    * assumed).  With 17..32 rows and K > 2048 dia_gemm splits K by itself when nstrips * (KT / 64) * 512 floats fit. */
   int64_t sk_scratch_floats;
+  /* zero-skipping weight stream of an unstructured-pruned matrix (dia_hip.layout.sparse_tile_weight) instead of W:
+   * sp_blocks = concatenated tile blocks, sp_toff[strip * KT + ktile] = (block offset / 16) << 8 | chunks.
+   * M <= 4, KT in {16, 32, 64}, no split-K; results are bit-identical to the dense tiles of the same matrix. */
+  const void* sp_blocks;
+  const uint32_t* sp_toff;
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the

@@ -12,6 +12,7 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--prefetch", type=int, default=0)
 ap.add_argument("--same", type=int, default=0)
 ap.add_argument("--sk", type=int, default=0)
+ap.add_argument("--sparse", type=float, default=0.0, help="fraction of zero weights -> zero-skipping stream")
 a = ap.parse_args()
 d = torch.device("cuda:0")
 K, N, epi = {"wi": (2048, 16384, hb.EPI_SWIGLU_EMIT), "wo": (8192, 2048, hb.EPI_RESID_EMIT), "o": (2048, 2048, hb.EPI_RESID_EMIT),
@@ -21,6 +22,13 @@ K, N, epi = {"wi": (2048, 16384, hb.EPI_SWIGLU_EMIT), "wo": (8192, 2048, hb.EPI_
 M = a.M
 mpad = (M + 15) // 16 * 16
 Ws = [torch.randint(-30000, 30000, (N // 16, K // 32, 64, 8), dtype=torch.int16, device=d).view(torch.bfloat16) for _ in range(18)]
+SP = None
+if a.sparse > 0:
+    SP = []
+    for Wd in Ws:
+        Wd.view(torch.int16)[torch.rand(Wd.shape, device=d) < a.sparse] = 0
+        SP.append(lay.sparse_tile_weight(Wd))
+    print("stream bytes", SP[0][0].numel(), "dense", Ws[0].numel() * 2)
 x = torch.randn(M, K, device=d)
 A = lay.pack_planes(x)
 ssq = torch.ones(K // 16, mpad, device=d)
@@ -35,6 +43,9 @@ def launch(W):
     g = hb.GemmArgs()
     g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
     g.W, g.KT, g.nstrips, g.epi, g.nw = hb.ptr(W), K // 32, N // 16, epi, a.nw
+    if SP is not None:
+        i = next(j for j, x_ in enumerate(Ws) if x_ is W)
+        g.W, g.sp_blocks, g.sp_toff = None, hb.ptr(SP[i][0]), hb.ptr(SP[i][1])
     if epi != hb.EPI_RESID_EMIT:
         g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq), K // 16, 1.0 / K, 1e-5
     g.ssq_ld = mpad

@@ -129,6 +129,64 @@ def test_gemm_split_k_resid(M, K, D, sk):
     assert torch.equal(lay.unpack_planes(outs[0][1], M, D), outs[0][0] * gn)
 
 
+@pytest.mark.parametrize("M,K,N,epi", [(2, 2048, 4096, "swiglu"), (4, 2048, 2048, "resid"), (1, 1024, 1024, "store"), (2, 512, 4096, "swiglu")])
+def test_gemv_sparse_stream(M, K, N, epi):
+    """unstructured-pruned matrix as a zero-skipping stream (layout.sparse_tile_weight): bit-identical to the dense
+    tiles of the same matrix, through every epilogue; a dense corner exercises the raw-tile escape."""
+    d = dev()
+    torch.manual_seed(K + N + M)
+    W = bf16r(torch.randn(K, N, device=d) * 0.05)
+    W[torch.rand_like(W) < 0.5] = 0
+    W[: 64, : 32] = bf16r(torch.randn(64, 32, device=d) * 0.05 + 0.5)          # fully dense tiles -> stored raw
+    W[: 64, N // 2: N // 2 + 32] = bf16r(torch.randn(64, 32, device=d) * 0.05 + 0.5)   # (the "up" half too, for the interleaved wi layout)
+    x = torch.randn(M, K, device=d)
+    mpad = 16
+    ssq = strip_ssq(x, mpad)
+    A = lay.pack_planes(x)
+    if epi == "swiglu":
+        Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(W.reshape(K, 2, N // 2)))
+    else:
+        Wt, kt, ns = lay.tile_weight(W)
+    blocks, toff = lay.sparse_tile_weight(Wt)
+    assert int(((toff & 255) == 0).sum()) >= 1 and blocks.numel() < 0.7 * Wt.numel() * 2
+    gn = bf16r(1.0 + 0.1 * torch.randn(N, device=d))
+    outs = []
+    for sparse in (False, True):
+        g = hb.GemmArgs()
+        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+        g.KT, g.nstrips = kt, ns
+        if sparse:
+            g.sp_blocks, g.sp_toff = hb.ptr(blocks), hb.ptr(toff)
+        else:
+            g.W, g.nw = hb.ptr(Wt), 16                 # the same 16-wave K split as the sparse kernel: identical summation order
+        g.ssq_ld = mpad
+        out = torch.zeros(mpad, N, device=d)
+        P = torch.zeros(3, 1, max(N // 32, 1), 64, 8, dtype=torch.bfloat16, device=d)
+        sso = torch.zeros(ns, mpad, device=d)
+        if epi == "swiglu":
+            g.epi = hb.EPI_SWIGLU_EMIT
+            g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq), K // 16, 1.0 / K, 1e-5
+            g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), P.shape[2]
+        elif epi == "resid":
+            g.epi = hb.EPI_RESID_EMIT
+            out[:M] = torch.randn(M, N, device=d, generator=torch.Generator(device=d).manual_seed(1))
+            g.out, g.ldo, g.gnext = hb.ptr(out), N, hb.ptr(gn)
+            g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), P.shape[2], hb.ptr(sso)
+        else:
+            g.epi = hb.EPI_SCALE_STORE
+            g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq), K // 16, 1.0 / K, 1e-5
+            g.out, g.ldo = hb.ptr(out), N
+        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+        torch.cuda.synchronize()
+        outs.append((out.clone(), P.clone(), sso.clone()))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+    if epi == "store":
+        xd = x.double()
+        ref = (xd @ W.double()) * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+        assert (outs[1][0][:M].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("M", [17, 20, 32])
 def test_gemm_two_mtiles(M, monkeypatch):
     """17..32 rows (batch 9-16): k_gemm32 — both m-tiles' A fragments in registers; K = 2048 in one workgroup
