@@ -415,7 +415,10 @@ __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
   const int head_row = by;
   const int NZ = gridDim.z;
   const int ngran = (nkeys + 31) >> 5;
-  const int nchunks = min(NZ, max(1, (ngran + NWV * p.gpw - 1) / (NWV * p.gpw)));   // workgroups that take keys
+  // up to 256 keys stay in ONE workgroup (two granules per wave, the second prefetched): no slab hand-off at all,
+  // 7.1 vs 8.1 us at 200 keys; beyond that the keys are split, one granule per wave and round
+  const int gpw = (ngran <= 2 * NWV) ? max(p.gpw, 2) : p.gpw;
+  const int nchunks = min(NZ, max(1, (ngran + NWV * gpw - 1) / (NWV * gpw)));   // workgroups that take keys
   if (chunk >= nchunks) return;
   ASTAMP(1);
   if (p.head_map) {
