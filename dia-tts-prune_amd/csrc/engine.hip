@@ -145,9 +145,13 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     int wo_sk = (R <= 4 && L.kt_wo % 2 == 0) ? 2 : ((R <= 16 && L.kt_wo % 4 == 0) ? 4 : 1);
     if (const char* ev = getenv("DIA_DBG_WO_SK")) wo_sk = atoi(ev) >= 1 && atoi(ev) <= 4 ? atoi(ev) : wo_sk;
     g.sk = wo_sk; g.sk_scratch = wo_sk > 1 ? d.sk_scratch : nullptr; g.sk_tickets = wo_sk > 1 ? d.sk_tickets : nullptr;
-    if (R > 16 && R <= 32) {      // two m-tiles: dia_gemm splits K = 8192 four ways by itself (k_gemm32)
-      g.sk = 1; g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets;
+    bool wo_pair = false;
+    if (R > 16 && R <= 32) {      // two m-tiles: split-K 4 over both m-tiles (paired k_gemm16) when the scratch covers it,
+      g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets;    // else dia_gemm splits K by itself (k_gemm32)
       g.sk_scratch_floats = d.sk_scratch_floats > 0 ? d.sk_scratch_floats : (int64_t)(d.D / 16) * 4 * 512;
+      wo_pair = L.kt_wo % 4 == 0 && g.sk_scratch_floats >= (int64_t)2 * L.ns_wo * 4 * 256 &&
+                !(getenv("DIA_DBG_WO_PAIR") && atoi(getenv("DIA_DBG_WO_PAIR")) == 0);
+      g.sk = wo_pair ? 4 : 1;
     }
     if (const char* ev = getenv("DIA_DBG_WO_NW")) g.nw = atoi(ev);
     if (const char* ev = getenv("DIA_DBG_WO_SPW")) g.spw = atoi(ev);
@@ -168,7 +172,11 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     lend_scratch(gi);
     if ((rc = dia_gemm(&gi, st))) return rc; mark(e, n++);
     rc = dia_gemm(&g, st);
-    if (rc == DIA_E_ARG && g.sk > 1) { g.sk = 1; g.sk_scratch = nullptr; g.sk_tickets = nullptr; rc = dia_gemm(&g, st); }
+    if (rc == DIA_E_ARG && g.sk > 1) {
+      g.sk = 1;
+      if (!wo_pair) { g.sk_scratch = nullptr; g.sk_tickets = nullptr; }     // two m-tiles keep the lent scratch
+      rc = dia_gemm(&g, st);
+    }
     if (rc) return rc;
     mark(e, n++);
   }

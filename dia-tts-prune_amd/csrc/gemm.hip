@@ -27,6 +27,7 @@
 #include "errors.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -65,6 +66,7 @@ struct GemmK {
   int kv_vblocked;
   const int* row_b; const int* seg_off;   // CROSSKV over a packed batch
   const unsigned char* sp_blocks; const unsigned int* sp_toff;   // zero-skipping weight stream (k_gemv_sparse)
+  int mz;                                  // host side only: m-tiles a k_gemm16 launch covers through gridDim.z (0/1 = one)
 };
 
 __device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v) {
@@ -863,6 +865,19 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
   float* inv_s = tile + 16 * 17;                                           // [16]
   constexpr int NT = NW * 64;
 
+  // 17..32 rows (batch 9-16): gridDim.z = 2, one m-tile per z.  The two workgroups of a pair stream the same weights
+  // at the same time from different CUs of ONE XCD (gridDim.x * gridDim.y is a multiple of 8), so HBM sees each
+  // byte once and the second reader is served by that XCD's L2; everything row-indexed is shifted by 16 rows.
+  if (gridDim.z > 1) {
+    const int z = blockIdx.z;
+    p.A += (long)z * p.a_ktiles * 512;
+    p.M = min(16, p.M - 16 * z);
+    if (p.ssq_in) p.ssq_in += 16 * z;
+    if (p.out) p.out += (long)16 * z * p.ldo;
+    if (p.P) p.P += (long)z * p.p_ktiles * 512;
+    if (p.ssq_out) p.ssq_out += 16 * z;
+    if (p.sk_scratch) { p.sk_scratch += (long)z * p.nstrips * gridDim.y * 256; p.sk_tickets += z * p.nstrips; }
+  }
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kt0 = blockIdx.y * (NW * KPW) + w * KPW;      // split-K over gridDim.y
   const int G = gridDim.x;
@@ -1496,6 +1511,156 @@ int launch_tile_ws(const GemmK& k, hipStream_t st) {
   return dia_check_launch("k_gemm_tile_ws");
 }
 
+// 17..32 rows in decode (batch 9-16).  With two m-tiles the activation image (3 planes x 32 rows x K) is 393 KB at
+// K = 2048: a workgroup that splits K over its waves for ONE strip pulls all of it through L2 -> CU for 64 KB of
+// weights.  Here the waves own STRIPS (WS each: a 32-row x 128*WS-column block per workgroup) and K is cut into
+// ranges of KR k-tiles, one workgroup each (gridDim.z), so a workgroup needs only its range of the image, shared
+// by its 8 waves through LDS.  A range is short (8-16 k-tiles), so nothing is pipelined: every load of the
+// workgroup — the image pieces first, then all KR*WS weight tiles of each wave — is issued at once, the pieces go
+// to LDS while the weights are still in flight (vmcnt retires in order), one barrier, then the MFMAs.  The partial
+// blocks (same lane <-> same output element in every range) meet once: coherent slab stores, a ticket per column
+// block, the last arriver adds the slabs in range order (bit-reproducible) and runs the epilogues.
+template <int KR, int WS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_blk32(GemmK p) {
+  constexpr int NW = 8, MT = 2;
+  constexpr int NA = KR * DIA_NPLANES * MT * 64;                               // 16-byte pieces of one K range of the image
+  constexpr int NPIECE = NA / 512;
+  constexpr int FPT = MT * WS * 4;                                             // partial sums per thread
+  static_assert(NA % 512 == 0, "pieces per thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* abuf = reinterpret_cast<u32x4*>(smem_raw);                            // [KR][3][MT][64] x 16 B
+  float* tiles = reinterpret_cast<float*>(smem_raw + (size_t)NA * 16);         // [NW][2][16][17]
+  float* inv_s = tiles + NW * 2 * 16 * 17;                                     // [32]
+  __shared__ int sk_flag;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int SK = gridDim.z, ks = blockIdx.z;
+  const int ktb = ks * KR;                                                     // first k-tile of this workgroup's range
+  const int s0 = blockIdx.x * (NW * WS) + w * WS;
+
+  u32x4 areg[NPIECE];
+#pragma unroll
+  for (int j = 0; j < NPIECE; ++j) {                                           // piece i -> (k-tile, plane, m-tile, lane) = its LDS slot
+    const int i = tid + 512 * j;
+    const int ln = i & 63, blk = i >> 6, mt = blk % MT, pl = (blk / MT) % DIA_NPLANES, kk = blk / (MT * DIA_NPLANES);
+    const int row = min(mt * 16 + (ln & 15), p.M - 1);                          // rows >= M alias the last valid row
+    areg[j] = *reinterpret_cast<const u32x4*>(p.A + pl * p.a_plane_stride + (((long)(row >> 4) * p.a_ktiles + ktb + kk) * 64 + ((ln & 48) | (row & 15))) * 8);
+  }
+  const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + lane;
+  bf16x8 b[KR][WS];
+  long woff[WS];
+#pragma unroll
+  for (int j = 0; j < WS; ++j) woff[j] = ((long)min(s0 + j, p.nstrips - 1) * p.KT + ktb) * 64;   // clamped for the loads
+#pragma unroll
+  for (int kk = 0; kk < KR; ++kk)                 // in the order the MFMAs consume them
+#pragma unroll
+    for (int j = 0; j < WS; ++j) b[kk][j] = DIA_WLOAD(Wl + woff[j] + (long)kk * 64);
+  if (tid < 256) {                              // row scales of the 32 rows: 8 threads per row, fixed order
+    const int r = tid >> 3, part = tid & 7;
+    float sA = 0.f;
+    if (p.ssq_in != nullptr && r < p.M)
+      for (int i = part; i < p.ssq_in_n; i += 8) sA += p.ssq_in[(long)i * p.ssq_ld + r];
+    sA += __shfl_xor(sA, 1, 64);
+    sA += __shfl_xor(sA, 2, 64);
+    sA += __shfl_xor(sA, 4, 64);
+    if (part == 0) inv_s[r] = (p.ssq_in != nullptr) ? rsqrtf(sA * p.inv_d + p.eps) : 1.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < NPIECE; ++j) abuf[tid + 512 * j] = areg[j];
+  lds_barrier();                                // image range + row scales visible; the weight loads stay in flight
+
+  f32x4 acc[MT][WS];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < WS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < KR; ++kk)
+#pragma unroll
+    for (int pl = 0; pl < DIA_NPLANES; ++pl)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, abuf[((kk * DIA_NPLANES + pl) * MT + i) * 64 + lane]);
+#pragma unroll
+        for (int j = 0; j < WS; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[kk][j], acc[i][j], 0, 0, 0);
+      }
+
+  // ---- one hand-off for the whole block: every lane's FPT partial sums, same mapping in every K range
+  if (SK > 1) {
+    // slab = [FPT / 2][512 threads][2 floats]: a wave's store instruction covers 512 contiguous bytes
+    float* slab = p.sk_scratch + ((long)blockIdx.x * SK + ks) * (512 * FPT) + tid * 2;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < WS; ++j) {
+        st2_agent(slab + ((i * WS + j) * 2) * 1024, acc[i][j][0], acc[i][j][1]);
+        st2_agent(slab + ((i * WS + j) * 2 + 1) * 1024, acc[i][j][2], acc[i][j][3]);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int ticket = __hip_atomic_fetch_add(p.sk_tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == SK - 1;
+      if (last) __hip_atomic_store(p.sk_tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      sk_flag = last;
+    }
+    __syncthreads();
+    if (!sk_flag) return;
+    const float* base = p.sk_scratch + (long)blockIdx.x * SK * (512 * FPT) + tid * 2;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < WS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < SK; ++k)                                   // range order: deterministic
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < WS; ++j) {
+          const float* s = base + (long)k * (512 * FPT) + ((i * WS + j) * 2) * 1024;
+          const float2 lo = ld2_agent(s), hi = ld2_agent(s + 1024);
+          acc[i][j][0] += lo.x; acc[i][j][1] += lo.y; acc[i][j][2] += hi.x; acc[i][j][3] += hi.y;
+        }
+  }
+  // ---- epilogue per wave, two 16x16 tiles at a time through this wave's LDS tiles: the two strips of one m-tile
+  // (WS = 2) or the two m-tiles of the one strip (WS = 1)
+  float* tw = tiles + w * (2 * 16 * 17);
+  const int et = lane >> 5, e_r = (lane >> 1) & 15, half = lane & 1;
+  const int col = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int it = 0; it < MT * WS / 2; ++it) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = WS == 2 ? it : t, j = WS == 2 ? t : 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tw[t * (16 * 17) + (r0 + r) * 17 + col] = acc[i][j][r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int mtl = WS == 2 ? it : et;
+    const int m = mtl * 16 + e_r;
+    const int strip = s0 + (WS == 2 ? et : 0);
+    const bool live = m < p.M && strip < p.nstrips;
+    const int n0 = strip * 16 + half * 8;
+    float xpre[8], gpre[8];
+    if (p.epi == DIA_EPI_RESID_EMIT && live) {
+      const float* o = p.out + (long)m * p.ldo + n0;
+      const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+      xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
+      xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) gpre[jj] = p.gnext ? p.gnext[n0 + jj] : 1.0f;
+    }
+    run_epilogue(p, tw + et * (16 * 17) + e_r * 17, inv_s[m], m, n0, half, min(strip, p.nstrips - 1), live, xpre, gpre);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int KR, int WS>
+int launch_blk32(const GemmK& k, hipStream_t st) {
+  constexpr size_t smem = (size_t)KR * DIA_NPLANES * 2 * 64 * 16 + sizeof(float) * (8 * 2 * 16 * 17 + 32);
+  launch_kernel(k_gemm_blk32<KR, WS>, dim3((k.nstrips + 8 * WS - 1) / (8 * WS), 1, k.KT / KR), dim3(512), smem, st, k);
+  return dia_check_launch("k_gemm_blk32");
+}
+
 template <int KC, int PD, int WPE, int NWT>
 int launch_tile_v(const GemmK& k, hipStream_t st) {
   const int mgroups = ((k.M + 15) / 16 + GT_MT - 1) / GT_MT;
@@ -1525,14 +1690,22 @@ int launch_g16(const GemmK& k, hipStream_t st) {
   const size_t smem = sizeof(f32x4) * NW * 64 + sizeof(float) * (16 * 17 + 16);
   const int sk = k.KT / (NW * KPW);
   int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
+  const int mz = k.mz > 1 ? 2 : 1;
+  // between one and four rounds of workgroups: walk the strips with about one workgroup per CU instead (logits, 579
+  // strips at 16 rows: 16.1 -> 10.9 us with three strips per workgroup)
+  if (mz == 1 && k.spw <= 0 && sk == 1 && k.nstrips > 256 && k.nstrips < 1024) spw = (k.nstrips + 255) / 256;
+  // two m-tiles: about 256 workgroups in all (one per CU, both halves of every pair resident together)
+  if (mz == 2 && k.spw <= 0) { const int per = 128 / sk > 0 ? 128 / sk : 1; spw = (k.nstrips + per - 1) / per; }
   if (const char* e = getenv("DIA_DBG_SPW")) spw = atoi(e);
   if constexpr (!(NW == 16 && KPW >= 4)) {
     if (spw > 1) {      // persistent multi-strip form, with or without split-K: A fragments loaded once per workgroup
-      launch_kernel(k_gemm16<NW, KPW, true>, dim3((k.nstrips + spw - 1) / spw, sk), dim3(NW * 64), smem, st, k);
+      int gx = (k.nstrips + spw - 1) / spw;
+      if (mz == 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
+      launch_kernel(k_gemm16<NW, KPW, true>, dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
       return dia_check_launch("k_gemm16");
     }
   }
-  launch_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
+  launch_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips, sk, mz), dim3(NW * 64), smem, st, k);
   return dia_check_launch("k_gemm16");
 }
 
@@ -1692,6 +1865,7 @@ static int fill_gemmk(const dia_gemm_args* a, GemmK& k) {
   k.sk_scratch = a->sk_scratch; k.sk_tickets = a->sk_tickets; k.kv_vblocked = a->kv_vblocked;
   k.row_b = a->row_b; k.seg_off = a->seg_off;
   k.sp_blocks = (const unsigned char*)a->sp_blocks; k.sp_toff = (const unsigned int*)a->sp_toff;
+  k.mz = 0;
   return DIA_OK;
 }
 
@@ -1787,6 +1961,35 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
       bool handled = false;
       int rc = launch_g16_any(k, nw16, sk, st, handled);
       if (handled) return rc;
+    }
+  }
+  // 17..32 rows: the one-m-tile kernel over both m-tiles at once (gridDim.z = 2, pairs share their weight stream through
+  // L2).  Split-K (a->sk > 1) needs scratch for both m-tiles: 2 * nstrips * sk * 256 floats, 2 * nstrips tickets.
+  if (mtiles == 2 && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext) &&
+      !(getenv("DIA_DBG_PAIR16") && atoi(getenv("DIA_DBG_PAIR16")) == 0) &&
+      (sk == 1 || a->sk_scratch_floats >= (int64_t)2 * a->nstrips * sk * 256)) {
+    const int ktl16 = a->KT / sk;
+    int nw16 = a->nw ? a->nw : ((ktl16 % 8 == 0 && ktl16 / 8 <= 8) ? 8 : ((ktl16 % 16 == 0 && ktl16 / 16 <= 4) ? 16 : 0));
+    if (nw16) {
+      bool handled = false;
+      k.mz = 2;
+      int rc = launch_g16_any(k, nw16, sk, st, handled);
+      k.mz = 0;
+      if (handled) return rc;
+    }
+  }
+  // 17..32 rows: column blocks x K ranges (k_gemm_blk32) when the caller lends split-K scratch holding
+  // (column blocks) * (K ranges) * 512 * 8*WS floats and a ticket per column block.  Opt-in: DIA_DBG_BLK32 = "KR,WS"
+  // (measured at 32 rows: wi 27.4 us, wo 20.1, o 10.5 against 20.9 / 21.3 / 6.9 for the paired kernel above).
+  if (mtiles == 2 && a->epi != DIA_EPI_CROSSKV && a->sk <= 1 && a->sk_scratch && a->sk_tickets && getenv("DIA_DBG_BLK32")) {
+    int kr = 16, ws = a->nstrips >= 512 ? 2 : 1;
+    { const char* e = getenv("DIA_DBG_BLK32"); kr = atoi(e); const char* c = strchr(e, ','); if (c) ws = atoi(c + 1); }
+    if ((kr == 8 || kr == 16) && (ws == 1 || ws == 2) && a->KT % kr == 0) {
+      const int64_t need = (int64_t)((a->nstrips + 8 * ws - 1) / (8 * ws)) * (a->KT / kr) * 512 * 8 * ws;
+      if (a->KT == kr || a->sk_scratch_floats >= need) {
+        if (kr == 16) return ws == 2 ? launch_blk32<16, 2>(k, st) : launch_blk32<16, 1>(k, st);
+        return ws == 2 ? launch_blk32<8, 2>(k, st) : launch_blk32<8, 1>(k, st);
+      }
     }
   }
   // 17..32 rows: two m-tiles with register-resident A (8 waves x 8 k-tiles = K 2048 per workgroup); longer K is

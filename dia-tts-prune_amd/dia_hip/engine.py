@@ -270,6 +270,9 @@ class DecodeSession:
         # split-K slabs: up to 4 splits of wo (one or two m-tiles); with 17..32 rows every GEMM splits K in two
         ns_max = max([self.D // 16, w.logits.ns] + [DL[k].ns for DL in w.dec_layers for k in ("qkv", "o", "cq", "co", "wi", "wo")])
         n_scr = max((self.D // 16) * 4 * 512, ns_max * 2 * 512 if 16 < self.R <= 32 else 0)
+        if 16 < self.R <= 32:    # k_gemm_blk32: column blocks x K ranges of >= 8 k-tiles, 512 floats per strip and range
+            n_scr = max([n_scr, w.logits.ns * -(-w.logits.kt // 8) * 512] +
+                        [DL[k].ns * -(-DL[k].kt // 8) * 512 for DL in w.dec_layers for k in ("qkv", "o", "cq", "co", "wi", "wo")])
         self.sk_scratch = z(n_scr)
         self.sk_tickets = z(ns_max, dt=torch.int32)
         self.mlp_barrier = z(2, dt=torch.int32)          # dia_mlp_fused: arrivals, error flag

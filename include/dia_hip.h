@@ -97,7 +97,8 @@ typedef struct {
   const int32_t* strip_map;
   /* cross-workgroup split-K (long K, few strips; one m-tile only): sk_scratch holds nstrips*sk*256 floats,
    * sk_tickets nstrips int32 zeroed once by the caller (the kernel re-zeroes them).  sk: 0 or 1 = off,
-   * n > 1 = n workgroups per strip (opt-in: measured slower than 1 on the decode shapes). */
+   * n > 1 = n workgroups per strip (opt-in: measured slower than 1 on the decode shapes).  With 17..32 rows
+   * (two m-tiles) both sizes double and sk_scratch_floats must state the capacity. */
   float* sk_scratch;
   int32_t* sk_tickets;
   int32_t sk;
@@ -107,7 +108,8 @@ typedef struct {
   const int32_t* row_b;
   const int32_t* seg_off;
   /* capacity of sk_scratch in floats (0 = not stated: only the explicit `sk` split-K, nstrips * sk * 256 floats, is
-   * assumed).  With 17..32 rows and K > 2048 dia_gemm splits K by itself when nstrips * (KT / 64) * 512 floats fit. */
+   * assumed).  With 17..32 rows and K > 2048 dia_gemm splits K by itself when nstrips * (KT / 64) * 512 floats fit;
+   * the column-block form (k_gemm_blk32, debug knob) needs nstrips * (KT / 8) * 512 floats. */
   int64_t sk_scratch_floats;
   /* zero-skipping weight stream of an unstructured-pruned matrix (dia_hip.layout.sparse_tile_weight) instead of W:
    * sp_blocks = concatenated tile blocks, sp_toff[strip * KT + ktile] = (block offset / 16) << 8 | chunks.

@@ -12,6 +12,7 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--prefetch", type=int, default=0)
 ap.add_argument("--same", type=int, default=0)
 ap.add_argument("--sk", type=int, default=0)
+ap.add_argument("--lend", type=int, default=0, help="lend split-K scratch (floats per strip and k-tile/8) so dia_gemm may pick k_gemm_blk32 at 17..32 rows")
 ap.add_argument("--sparse", type=float, default=0.0, help="fraction of zero weights -> zero-skipping stream")
 a = ap.parse_args()
 d = torch.device("cuda:0")
@@ -38,7 +39,8 @@ ssq_out = torch.zeros(N // 16, mpad, device=d)
 gn = torch.ones(N, device=d)
 L = hb.lib()
 st = torch.cuda.Stream()
-skscr = torch.zeros((N // 16) * 8 * 256, device=d); sktk = torch.zeros(N // 16, dtype=torch.int32, device=d)
+skscr = torch.zeros(2 * (N // 16) * 8 * 256, device=d); sktk = torch.zeros(2 * (N // 16), dtype=torch.int32, device=d)
+lendscr = torch.zeros((N // 16) * (K // 256) * 512, device=d) if a.lend else None
 def launch(W):
     g = hb.GemmArgs()
     g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
@@ -52,7 +54,9 @@ def launch(W):
     g.out, g.ldo, g.gnext = hb.ptr(out), out.shape[1], hb.ptr(gn)
     g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), P.shape[2], hb.ptr(ssq_out)
     if a.sk > 1:
-        g.sk_scratch, g.sk_tickets, g.sk = hb.ptr(skscr), hb.ptr(sktk), a.sk
+        g.sk_scratch, g.sk_tickets, g.sk, g.sk_scratch_floats = hb.ptr(skscr), hb.ptr(sktk), a.sk, skscr.numel()
+    elif a.lend:
+        g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = hb.ptr(lendscr), hb.ptr(sktk), lendscr.numel()
     hb.check(L.dia_gemm(C.byref(g), C.c_void_p(st.cuda_stream)), "gemm")
 if a.same: Ws = Ws[:1] * 18
 for W in Ws: launch(W)

@@ -193,6 +193,7 @@ def test_gemm_two_mtiles(M, monkeypatch):
     (selected by a debug knob only: it loses to the generic kernel), K = 8192 split four ways by dia_gemm itself
     when the scratch capacity is stated."""
     monkeypatch.setenv("DIA_DBG_G32_ALL", "1")
+    monkeypatch.setenv("DIA_DBG_PAIR16", "0")        # not the paired one-m-tile kernel (test_gemm_paired_mtiles)
     d = dev()
     torch.manual_seed(M)
     # SCALE_STORE with the row norm, K = 2048
@@ -290,6 +291,198 @@ def test_gemm_two_mtiles(M, monkeypatch):
     assert torch.equal(lay.unpack_planes(outs[0][1], M, D), outs[0][0] * gn)
     want = (outs[0][0].double() ** 2).reshape(M, D // 16, 16).sum(-1).T
     assert (outs[0][2][:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
+
+
+@pytest.mark.parametrize("M", [17, 23, 32])
+def test_gemm_paired_mtiles(M, monkeypatch):
+    """17..32 rows (batch 9-16), default path: the one-m-tile kernel launched over both m-tiles (gridDim.z = 2).
+    Every epilogue, persistent and one-strip forms, split-K 4; rows 0..15 must equal the 16-row launch bit for bit
+    (same kernel, same summation order), rows 16.. the 16-row launch on those rows."""
+    monkeypatch.delenv("DIA_DBG_PAIR16", raising=False)
+    d = dev()
+    torch.manual_seed(200 + M)
+    L = hb.lib()
+
+    def args(A, M_, Wt, kt, ns, epi):
+        g = hb.GemmArgs()
+        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M_
+        g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, epi
+        return g
+
+    # SCALE_STORE: K = 2048, N = 3072 (192 strips -> two strips per workgroup) and N = 592 (37 strips)
+    K = 2048
+    x = torch.randn(M, K, device=d) * 2.0
+    gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
+    xd = x.double()
+    inv = torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+    ss = strip_ssq(x, 32)
+    for N in (3072, 592):
+        W = bf16r(torch.randn(K, N, device=d) * 0.05)
+        Wt, kt, ns = lay.tile_weight(W)
+        outs = []
+        for rows in (slice(0, M), slice(0, 16), slice(16, M)):
+            xs = x[rows]
+            A = lay.pack_planes(xs * gw)
+            out = torch.full((xs.shape[0], N), float("nan"), device=d)
+            sr = strip_ssq(xs, 32)
+            g = args(A, xs.shape[0], Wt, kt, ns, hb.EPI_SCALE_STORE)
+            g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(sr), K // 16, 1.0 / K, 1e-5, 32
+            g.out, g.ldo = hb.ptr(out), N
+            hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
+            torch.cuda.synchronize()
+            outs.append(out)
+        ref = ((xd * gw.double()) @ W.double()) * inv
+        assert (outs[0].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+        assert torch.equal(outs[0][:16], outs[1])
+        if M - 16 > 4:                  # (up to 4 rows take the GEMV kernel: another K split, another summation order)
+            assert torch.equal(outs[0][16:], outs[2])
+    # SWIGLU_EMIT: F = 8192 (1024 strips, eight per workgroup) and F = 1024
+    A = lay.pack_planes(x * gw)
+    h = (xd * inv) * gw.double()
+    for F in (8192, 1024):
+        wi = bf16r(torch.randn(K, 2, F, device=d) * 0.05)
+        Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi))
+        P = torch.zeros(3, 2, F // 32, 64, 8, dtype=torch.bfloat16, device=d)
+        g = args(A, M, Wt, kt, ns, hb.EPI_SWIGLU_EMIT)
+        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, 32
+        g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), F // 32
+        hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
+        torch.cuda.synchronize()
+        f = torch.einsum("mk,kgf->mgf", h, wi.double())
+        ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
+        assert (lay.unpack_planes(P, M, F).double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # RESID_EMIT: (K, D, sk) = o-like, wo-like with split-K 4 over both m-tiles, a small ragged one
+    for K2, D, sk in ((2048, 2048, 0), (8192, 2048, 4), (512, 272, 0), (4096, 256, 2)):
+        a = torch.randn(M, K2, device=d)
+        W2 = bf16r(torch.randn(K2, D, device=d) * 0.03)
+        x0 = torch.randn(M, D, device=d)
+        gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+        Wt, kt, ns = lay.tile_weight(W2)
+        A2 = lay.pack_planes(a)
+        pkt = (D + 31) // 32
+        scr = torch.zeros(max(1, 2 * ns * max(sk, 1) * 256), device=d); tk = torch.zeros(2 * ns, dtype=torch.int32, device=d)
+        res = []
+        for _ in range(2):
+            xr = x0.clone()
+            P = torch.zeros(3, 2, pkt, 64, 8, dtype=torch.bfloat16, device=d)
+            ssq = torch.zeros(ns, 32, device=d)
+            g = args(A2, M, Wt, kt, ns, hb.EPI_RESID_EMIT)
+            g.ssq_ld, g.out, g.ldo, g.gnext = 32, hb.ptr(xr), D, hb.ptr(gn)
+            g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), pkt, hb.ptr(ssq)
+            if sk:
+                g.sk, g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = sk, hb.ptr(scr), hb.ptr(tk), scr.numel()
+            hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
+            torch.cuda.synchronize()
+            assert (tk == 0).all()
+            if sk:
+                assert scr[ns * sk * 256:].abs().sum().item() > 0      # the second m-tile used its own slabs
+            res.append((xr, P, ssq))
+        ref = x0.double() + a.double() @ W2.double()
+        assert (res[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+        assert torch.equal(lay.unpack_planes(res[0][1], M, pkt * 32)[:, :D], res[0][0] * gn)
+        want = (res[0][0].double() ** 2).reshape(M, D // 16, 16).sum(-1).T
+        assert (res[0][2][:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
+    # split-K without a stated capacity for both m-tiles is refused (as before), not run out of bounds
+    g = args(A2, M, Wt, kt, ns, hb.EPI_RESID_EMIT)
+    g.ssq_ld, g.out, g.ldo, g.gnext = 32, hb.ptr(xr), D, hb.ptr(gn)
+    g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), pkt, hb.ptr(ssq)
+    g.sk, g.sk_scratch, g.sk_tickets = 2, hb.ptr(scr), hb.ptr(tk)
+    assert L.dia_gemm(C.byref(g), None) != 0
+
+
+@pytest.mark.parametrize("form", ["16,2", "16,1", "8,2", "8,1"])
+@pytest.mark.parametrize("M", [17, 23, 32])
+def test_gemm_blk32(M, form, monkeypatch):
+    """17..32 rows (batch 9-16): k_gemm_blk32 — column blocks x K ranges, one slab hand-off per block.  All four
+    forms (k-tiles per range, strips per wave), the three decode epilogues, strip counts that are not whole
+    blocks, twice for bit-reproducibility, tickets re-armed."""
+    monkeypatch.setenv("DIA_DBG_BLK32", form)
+    monkeypatch.setenv("DIA_DBG_PAIR16", "0")
+    kr, ws = (int(v) for v in form.split(","))
+    d = dev()
+    torch.manual_seed(100 + M)
+
+    def lend(g, ns, kt):
+        blocks = (ns + 8 * ws - 1) // (8 * ws)
+        scr = torch.zeros(blocks * (kt // kr) * 512 * 8 * ws, device=d)
+        tk = torch.zeros(ns, dtype=torch.int32, device=d)
+        g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = hb.ptr(scr), hb.ptr(tk), scr.numel()
+        return scr, tk
+
+    # SCALE_STORE with the row norm: K = 2048, 37 strips (a partial last block)
+    K, N = 2048, 37 * 16
+    x = torch.randn(M, K, device=d) * 2.0
+    gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
+    W = bf16r(torch.randn(K, N, device=d) * 0.05)
+    Wt, kt, ns = lay.tile_weight(W)
+    A = lay.pack_planes(x * gw)
+    ss = strip_ssq(x, 32)
+    outs = []
+    for _ in range(2):
+        out = torch.full((M, N), float("nan"), device=d)
+        g = hb.GemmArgs()
+        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+        g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_SCALE_STORE
+        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, 32
+        g.out, g.ldo = hb.ptr(out), N
+        scr, tk = lend(g, ns, kt)
+        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+        torch.cuda.synchronize()
+        assert (tk == 0).all() and scr.abs().sum().item() > 0        # the split kernel ran and re-armed its tickets
+        outs.append(out)
+    xd = x.double()
+    ref = ((xd * gw.double()) @ W.double()) * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+    assert (outs[0].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(outs[0], outs[1])
+    # SWIGLU_EMIT: K = 2048, F = 2048 (256 strips)
+    F = 2048
+    wi = bf16r(torch.randn(K, 2, F, device=d) * 0.05)
+    Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi))
+    P = torch.zeros(3, 2, F // 32, 64, 8, dtype=torch.bfloat16, device=d)
+    g = hb.GemmArgs()
+    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+    g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_SWIGLU_EMIT
+    g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, 32
+    g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), F // 32
+    scr, tk = lend(g, ns, kt)
+    hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+    torch.cuda.synchronize()
+    assert (tk == 0).all()
+    h = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
+    f = torch.einsum("mk,kgf->mgf", h, wi.double())
+    ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
+    assert (lay.unpack_planes(P, M, F).double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # RESID_EMIT: K = 8192 (16 or 32 ranges), D = 2048; and K = 512 into D = 272 (17 strips)
+    for K2, D in ((8192, 2048), (512, 272)):
+        a = torch.randn(M, K2, device=d)
+        W2 = bf16r(torch.randn(K2, D, device=d) * 0.03)
+        x0 = torch.randn(M, D, device=d)
+        gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+        Wt, kt, ns = lay.tile_weight(W2)
+        A2 = lay.pack_planes(a)
+        pkt = (D + 31) // 32
+        res = []
+        for _ in range(2):
+            xr = x0.clone()
+            P = torch.zeros(3, 2, pkt, 64, 8, dtype=torch.bfloat16, device=d)
+            ssq = torch.zeros(ns, 32, device=d)
+            g = hb.GemmArgs()
+            g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A2), A2[0].numel(), A2.shape[2], M
+            g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_RESID_EMIT
+            g.ssq_ld, g.out, g.ldo, g.gnext = 32, hb.ptr(xr), D, hb.ptr(gn)
+            g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), pkt, hb.ptr(ssq)
+            scr, tk = lend(g, ns, kt)
+            hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+            torch.cuda.synchronize()
+            assert (tk == 0).all()
+            res.append((xr, P, ssq))
+        ref = x0.double() + a.double() @ W2.double()
+        assert (res[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+        assert torch.equal(lay.unpack_planes(res[0][1], M, pkt * 32)[:, :D], res[0][0] * gn)
+        want = (res[0][0].double() ** 2).reshape(M, D // 16, 16).sum(-1).T
+        assert (res[0][2][:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
 
 
 @pytest.mark.parametrize("M,K,F", [(2, 2048, 8192), (16, 256, 512), (33, 512, 1024)])
