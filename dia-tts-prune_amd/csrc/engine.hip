@@ -69,7 +69,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   const int nqkv = (d.q_heads + 2 * d.kv_heads) * 128;
   int n = 0, rc;
   // 17..32 rows: every GEMM may split K inside dia_gemm (k_gemm32 / k_gemm32m) when it is handed the scratch
-  const bool two_tiles = R > 16 && R <= 32 && d.sk_scratch && d.sk_tickets && d.sk_scratch_floats > 0;
+  const bool two_tiles = R > 16 && R <= 32 && d.sk_scratch && d.sk_tickets && d.sk_scratch_floats > 0;   // (k_gemm32 / k_gemm32m / blk32 only)
   auto lend_scratch = [&](dia_gemm_args& g) {
     if (two_tiles) { g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets; g.sk_scratch_floats = d.sk_scratch_floats; }
   };
@@ -146,10 +146,10 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     if (const char* ev = getenv("DIA_DBG_WO_SK")) wo_sk = atoi(ev) >= 1 && atoi(ev) <= 4 ? atoi(ev) : wo_sk;
     g.sk = wo_sk; g.sk_scratch = wo_sk > 1 ? d.sk_scratch : nullptr; g.sk_tickets = wo_sk > 1 ? d.sk_tickets : nullptr;
     bool wo_pair = false;
-    if (R > 16 && R <= 32) {      // two m-tiles: split-K 4 over both m-tiles (paired k_gemm16) when the scratch covers it,
-      g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets;    // else dia_gemm splits K by itself (k_gemm32)
+    if (R > 16 && R <= 64) {      // 2..4 m-tiles: split-K 4 over every m-tile (k_gemm16 with gridDim.z) when the scratch covers
+      g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets;    // it, else dia_gemm splits K by itself (two m-tiles: k_gemm32)
       g.sk_scratch_floats = d.sk_scratch_floats > 0 ? d.sk_scratch_floats : (int64_t)(d.D / 16) * 4 * 512;
-      wo_pair = L.kt_wo % 4 == 0 && g.sk_scratch_floats >= (int64_t)2 * L.ns_wo * 4 * 256 &&
+      wo_pair = L.kt_wo % 4 == 0 && g.sk_scratch_floats >= (int64_t)((R + 15) / 16) * L.ns_wo * 4 * 256 &&
                 !(getenv("DIA_DBG_WO_PAIR") && atoi(getenv("DIA_DBG_WO_PAIR")) == 0);
       g.sk = wo_pair ? 4 : 1;
     }

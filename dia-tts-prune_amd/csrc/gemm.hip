@@ -865,7 +865,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
   float* inv_s = tile + 16 * 17;                                           // [16]
   constexpr int NT = NW * 64;
 
-  // 17..32 rows (batch 9-16): gridDim.z = 2, one m-tile per z.  The two workgroups of a pair stream the same weights
+  // 17..64 rows (batch 9-32): gridDim.z = 2..4, one m-tile per z.  The workgroups of a group stream the same weights
   // at the same time from different CUs of ONE XCD (gridDim.x * gridDim.y is a multiple of 8), so HBM sees each
   // byte once and the second reader is served by that XCD's L2; everything row-indexed is shifted by 16 rows.
   if (gridDim.z > 1) {
@@ -1690,17 +1690,21 @@ int launch_g16(const GemmK& k, hipStream_t st) {
   const size_t smem = sizeof(f32x4) * NW * 64 + sizeof(float) * (16 * 17 + 16);
   const int sk = k.KT / (NW * KPW);
   int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
-  const int mz = k.mz > 1 ? 2 : 1;
+  const int mz = k.mz > 1 ? k.mz : 1;
   // between one and four rounds of workgroups: walk the strips with about one workgroup per CU instead (logits, 579
   // strips at 16 rows: 16.1 -> 10.9 us with three strips per workgroup)
   if (mz == 1 && k.spw <= 0 && sk == 1 && k.nstrips > 256 && k.nstrips < 1024) spw = (k.nstrips + 255) / 256;
   // two m-tiles: about 256 workgroups in all (one per CU, both halves of every pair resident together)
-  if (mz == 2 && k.spw <= 0) { const int per = 128 / sk > 0 ? 128 / sk : 1; spw = (k.nstrips + per - 1) / per; }
+  if (mz >= 2 && k.spw <= 0) {
+    int per = 256 / mz / sk;
+    per = per >= 8 ? per / 8 * 8 : (per > 0 ? per : 1);
+    spw = (k.nstrips + per - 1) / per;
+  }
   if (const char* e = getenv("DIA_DBG_SPW")) spw = atoi(e);
   if constexpr (!(NW == 16 && KPW >= 4)) {
     if (spw > 1) {      // persistent multi-strip form, with or without split-K: A fragments loaded once per workgroup
       int gx = (k.nstrips + spw - 1) / spw;
-      if (mz == 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
+      if (mz >= 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
       launch_kernel(k_gemm16<NW, KPW, true>, dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
       return dia_check_launch("k_gemm16");
     }
@@ -1963,16 +1967,18 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
       if (handled) return rc;
     }
   }
-  // 17..32 rows: the one-m-tile kernel over both m-tiles at once (gridDim.z = 2, pairs share their weight stream through
-  // L2).  Split-K (a->sk > 1) needs scratch for both m-tiles: 2 * nstrips * sk * 256 floats, 2 * nstrips tickets.
-  if (mtiles == 2 && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext) &&
-      !(getenv("DIA_DBG_PAIR16") && atoi(getenv("DIA_DBG_PAIR16")) == 0) &&
-      (sk == 1 || a->sk_scratch_floats >= (int64_t)2 * a->nstrips * sk * 256)) {
+  // 17..64 rows: the one-m-tile kernel over all m-tiles at once (gridDim.z = 2..4, the workgroups of a group share their
+  // weight stream through L2).  Split-K (a->sk > 1) needs scratch for every m-tile: mtiles * nstrips * sk * 256 floats,
+  // mtiles * nstrips tickets.  DIA_DBG_PAIR16 = highest m-tile count served this way (0 = off).
+  int pair_max = 4;
+  if (const char* e = getenv("DIA_DBG_PAIR16")) pair_max = atoi(e) == 1 ? 4 : atoi(e);
+  if (mtiles >= 2 && mtiles <= pair_max && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext) &&
+      (sk == 1 || a->sk_scratch_floats >= (int64_t)mtiles * a->nstrips * sk * 256)) {
     const int ktl16 = a->KT / sk;
     int nw16 = a->nw ? a->nw : ((ktl16 % 8 == 0 && ktl16 / 8 <= 8) ? 8 : ((ktl16 % 16 == 0 && ktl16 / 16 <= 4) ? 16 : 0));
     if (nw16) {
       bool handled = false;
-      k.mz = 2;
+      k.mz = mtiles;
       int rc = launch_g16_any(k, nw16, sk, st, handled);
       k.mz = 0;
       if (handled) return rc;

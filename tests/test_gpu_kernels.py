@@ -293,9 +293,9 @@ def test_gemm_two_mtiles(M, monkeypatch):
     assert (outs[0][2][:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
 
 
-@pytest.mark.parametrize("M", [17, 23, 32])
+@pytest.mark.parametrize("M", [17, 23, 32, 40, 64])
 def test_gemm_paired_mtiles(M, monkeypatch):
-    """17..32 rows (batch 9-16), default path: the one-m-tile kernel launched over both m-tiles (gridDim.z = 2).
+    """17..64 rows (batch 9-32), default path: the one-m-tile kernel launched over all m-tiles (gridDim.z = 2..4).
     Every epilogue, persistent and one-strip forms, split-K 4; rows 0..15 must equal the 16-row launch bit for bit
     (same kernel, same summation order), rows 16.. the 16-row launch on those rows."""
     monkeypatch.delenv("DIA_DBG_PAIR16", raising=False)
@@ -315,18 +315,20 @@ def test_gemm_paired_mtiles(M, monkeypatch):
     gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
     xd = x.double()
     inv = torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
-    ss = strip_ssq(x, 32)
+    MP = (M + 15) // 16 * 16
+    MT_ = MP // 16
+    ss = strip_ssq(x, MP)
     for N in (3072, 592):
         W = bf16r(torch.randn(K, N, device=d) * 0.05)
         Wt, kt, ns = lay.tile_weight(W)
         outs = []
-        for rows in (slice(0, M), slice(0, 16), slice(16, M)):
+        for rows in (slice(0, M), slice(0, 16), slice(MP - 16, M)):
             xs = x[rows]
             A = lay.pack_planes(xs * gw)
             out = torch.full((xs.shape[0], N), float("nan"), device=d)
-            sr = strip_ssq(xs, 32)
+            sr = strip_ssq(xs, MP)
             g = args(A, xs.shape[0], Wt, kt, ns, hb.EPI_SCALE_STORE)
-            g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(sr), K // 16, 1.0 / K, 1e-5, 32
+            g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(sr), K // 16, 1.0 / K, 1e-5, MP
             g.out, g.ldo = hb.ptr(out), N
             hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
             torch.cuda.synchronize()
@@ -334,17 +336,17 @@ def test_gemm_paired_mtiles(M, monkeypatch):
         ref = ((xd * gw.double()) @ W.double()) * inv
         assert (outs[0].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
         assert torch.equal(outs[0][:16], outs[1])
-        if M - 16 > 4:                  # (up to 4 rows take the GEMV kernel: another K split, another summation order)
-            assert torch.equal(outs[0][16:], outs[2])
+        if M - (MP - 16) > 4:           # (up to 4 rows take the GEMV kernel: another K split, another summation order)
+            assert torch.equal(outs[0][MP - 16:], outs[2])
     # SWIGLU_EMIT: F = 8192 (1024 strips, eight per workgroup) and F = 1024
     A = lay.pack_planes(x * gw)
     h = (xd * inv) * gw.double()
     for F in (8192, 1024):
         wi = bf16r(torch.randn(K, 2, F, device=d) * 0.05)
         Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi))
-        P = torch.zeros(3, 2, F // 32, 64, 8, dtype=torch.bfloat16, device=d)
+        P = torch.zeros(3, MT_, F // 32, 64, 8, dtype=torch.bfloat16, device=d)
         g = args(A, M, Wt, kt, ns, hb.EPI_SWIGLU_EMIT)
-        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, 32
+        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, MP
         g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), F // 32
         hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
         torch.cuda.synchronize()
@@ -360,14 +362,14 @@ def test_gemm_paired_mtiles(M, monkeypatch):
         Wt, kt, ns = lay.tile_weight(W2)
         A2 = lay.pack_planes(a)
         pkt = (D + 31) // 32
-        scr = torch.zeros(max(1, 2 * ns * max(sk, 1) * 256), device=d); tk = torch.zeros(2 * ns, dtype=torch.int32, device=d)
+        scr = torch.zeros(max(1, MT_ * ns * max(sk, 1) * 256), device=d); tk = torch.zeros(MT_ * ns, dtype=torch.int32, device=d)
         res = []
         for _ in range(2):
             xr = x0.clone()
-            P = torch.zeros(3, 2, pkt, 64, 8, dtype=torch.bfloat16, device=d)
-            ssq = torch.zeros(ns, 32, device=d)
+            P = torch.zeros(3, MT_, pkt, 64, 8, dtype=torch.bfloat16, device=d)
+            ssq = torch.zeros(ns, MP, device=d)
             g = args(A2, M, Wt, kt, ns, hb.EPI_RESID_EMIT)
-            g.ssq_ld, g.out, g.ldo, g.gnext = 32, hb.ptr(xr), D, hb.ptr(gn)
+            g.ssq_ld, g.out, g.ldo, g.gnext = MP, hb.ptr(xr), D, hb.ptr(gn)
             g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), pkt, hb.ptr(ssq)
             if sk:
                 g.sk, g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = sk, hb.ptr(scr), hb.ptr(tk), scr.numel()
@@ -375,7 +377,7 @@ def test_gemm_paired_mtiles(M, monkeypatch):
             torch.cuda.synchronize()
             assert (tk == 0).all()
             if sk:
-                assert scr[ns * sk * 256:].abs().sum().item() > 0      # the second m-tile used its own slabs
+                assert scr[(MT_ - 1) * ns * sk * 256:].abs().sum().item() > 0      # the last m-tile used its own slabs
             res.append((xr, P, ssq))
         ref = x0.double() + a.double() @ W2.double()
         assert (res[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
@@ -385,7 +387,7 @@ def test_gemm_paired_mtiles(M, monkeypatch):
         assert (res[0][2][:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
     # split-K without a stated capacity for both m-tiles is refused (as before), not run out of bounds
     g = args(A2, M, Wt, kt, ns, hb.EPI_RESID_EMIT)
-    g.ssq_ld, g.out, g.ldo, g.gnext = 32, hb.ptr(xr), D, hb.ptr(gn)
+    g.ssq_ld, g.out, g.ldo, g.gnext = MP, hb.ptr(xr), D, hb.ptr(gn)
     g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), pkt, hb.ptr(ssq)
     g.sk, g.sk_scratch, g.sk_tickets = 2, hb.ptr(scr), hb.ptr(tk)
     assert L.dia_gemm(C.byref(g), None) != 0
