@@ -146,7 +146,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     if (const char* ev = getenv("DIA_DBG_WO_SK")) wo_sk = atoi(ev) >= 1 && atoi(ev) <= 4 ? atoi(ev) : wo_sk;
     g.sk = wo_sk; g.sk_scratch = wo_sk > 1 ? d.sk_scratch : nullptr; g.sk_tickets = wo_sk > 1 ? d.sk_tickets : nullptr;
     bool wo_pair = false;
-    if (R > 16 && R <= 64) {      // 2..4 m-tiles: split-K 4 over every m-tile (k_gemm16 with gridDim.z) when the scratch covers
+    if (R > 16 && R <= 128) {     // 2..8 m-tiles: split-K 4 over every m-tile (k_gemm16 with gridDim.z) when the scratch covers
       g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets;    // it, else dia_gemm splits K by itself (two m-tiles: k_gemm32)
       g.sk_scratch_floats = d.sk_scratch_floats > 0 ? d.sk_scratch_floats : (int64_t)(d.D / 16) * 4 * 512;
       wo_pair = L.kt_wo % 4 == 0 && g.sk_scratch_floats >= (int64_t)((R + 15) / 16) * L.ns_wo * 4 * 256 &&

@@ -865,7 +865,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
   float* inv_s = tile + 16 * 17;                                           // [16]
   constexpr int NT = NW * 64;
 
-  // 17..64 rows (batch 9-32): gridDim.z = 2..4, one m-tile per z.  The workgroups of a group stream the same weights
+  // 17..128 rows (batch 9-64): gridDim.z = 2..8, one m-tile per z.  The workgroups of a group stream the same weights
   // at the same time from different CUs of ONE XCD (gridDim.x * gridDim.y is a multiple of 8), so HBM sees each
   // byte once and the second reader is served by that XCD's L2; everything row-indexed is shifted by 16 rows.
   if (gridDim.z > 1) {
@@ -1967,11 +1967,11 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
       if (handled) return rc;
     }
   }
-  // 17..64 rows: the one-m-tile kernel over all m-tiles at once (gridDim.z = 2..4, the workgroups of a group share their
+  // 17..128 rows: the one-m-tile kernel over all m-tiles at once (gridDim.z = 2..8, the workgroups of a group share their
   // weight stream through L2).  Split-K (a->sk > 1) needs scratch for every m-tile: mtiles * nstrips * sk * 256 floats,
   // mtiles * nstrips tickets.  DIA_DBG_PAIR16 = highest m-tile count served this way (0 = off).
-  int pair_max = 4;
-  if (const char* e = getenv("DIA_DBG_PAIR16")) pair_max = atoi(e) == 1 ? 4 : atoi(e);
+  int pair_max = 8;
+  if (const char* e = getenv("DIA_DBG_PAIR16")) pair_max = atoi(e) == 1 ? 8 : atoi(e);
   if (mtiles >= 2 && mtiles <= pair_max && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext) &&
       (sk == 1 || a->sk_scratch_floats >= (int64_t)mtiles * a->nstrips * sk * 256)) {
     const int ktl16 = a->KT / sk;

@@ -270,13 +270,13 @@ class DecodeSession:
         # split-K slabs: up to 4 splits of wo (one or two m-tiles); with 17..32 rows every GEMM splits K in two
         ns_max = max([self.D // 16, w.logits.ns] + [DL[k].ns for DL in w.dec_layers for k in ("qkv", "o", "cq", "co", "wi", "wo")])
         n_scr = max((self.D // 16) * 4 * 512, ns_max * 2 * 512 if 16 < self.R <= 32 else 0)
-        if 16 < self.R <= 64:    # 2..4 m-tiles: wo splits K four ways for every m-tile (k_gemm16 over gridDim.z)
+        if 16 < self.R <= 128:   # 2..8 m-tiles: wo splits K four ways for every m-tile (k_gemm16 over gridDim.z)
             n_scr = max(n_scr, -(-self.R // 16) * (self.D // 16) * 4 * 256)
         if 16 < self.R <= 32:    # k_gemm_blk32: column blocks x K ranges of >= 8 k-tiles, 512 floats per strip and range
             n_scr = max([n_scr, w.logits.ns * -(-w.logits.kt // 8) * 512] +
                         [DL[k].ns * -(-DL[k].kt // 8) * 512 for DL in w.dec_layers for k in ("qkv", "o", "cq", "co", "wi", "wo")])
         self.sk_scratch = z(n_scr)
-        self.sk_tickets = z(max(ns_max, 4 * (self.D // 16)), dt=torch.int32)
+        self.sk_tickets = z(max(ns_max, 8 * (self.D // 16)), dt=torch.int32)
         self.mlp_barrier = z(2, dt=torch.int32)          # dia_mlp_fused: arrivals, error flag
 
         # token buffer + state machine (state.py:178-208; model.py:736-741)

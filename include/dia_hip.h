@@ -342,9 +342,9 @@ typedef struct {
   const float* cos_t;       /* [T+1][64] */
   const float* sin_t;
   const int32_t* text_len;  /* [B] */
-  float* sk_scratch;        /* split-K slabs: at least (D/16)*4*512 floats; with 17..64 rows (batch 9-32) also
+  float* sk_scratch;        /* split-K slabs: at least (D/16)*4*512 floats; with 17..128 rows (batch 9-64) also
                              * ceil(rows/16) * (D/16) * 4 * 256 (wo splits K four ways for every m-tile) */
-  int32_t* sk_tickets;      /* max(max strips, 4 * D/16) int32, zeroed by the caller once */
+  int32_t* sk_tickets;      /* max(max strips, 8 * D/16) int32, zeroed by the caller once */
   float* attn_scratch;      /* max over self/cross of dia_attn_scratch_floats(...) floats */
   int32_t* attn_tickets;    /* max(R*kv_heads, B*cq_heads) int32, zeroed by the caller once */
   int64_t sk_scratch_floats;/* capacity of sk_scratch in floats (0 = the minimum above) */

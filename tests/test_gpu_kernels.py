@@ -293,7 +293,7 @@ def test_gemm_two_mtiles(M, monkeypatch):
     assert (outs[0][2][:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
 
 
-@pytest.mark.parametrize("M", [17, 23, 32, 40, 64])
+@pytest.mark.parametrize("M", [17, 23, 32, 40, 64, 100, 128])
 def test_gemm_paired_mtiles(M, monkeypatch):
     """17..64 rows (batch 9-32), default path: the one-m-tile kernel launched over all m-tiles (gridDim.z = 2..4).
     Every epilogue, persistent and one-strip forms, split-K 4; rows 0..15 must equal the 16-row launch bit for bit
