@@ -857,7 +857,7 @@ int launch_sparse(const GemmK& k, hipStream_t st) {
 // 5..16 rows (batch 3-8): one m-tile, A fragments held in registers for the workgroup's whole life
 // (each wave owns a fixed K range of KPW k-tiles = 12*KPW VGPRs) and reused for every strip the
 // workgroup walks; weight tiles double-buffered across strips like k_gemv_small.
-template <int NW, int KPW, bool MULTI>
+template <int NW, int KPW, bool MULTI, bool MZ = false>
 __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][64]
@@ -868,7 +868,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
   // 17..128 rows (batch 9-64): gridDim.z = 2..8, one m-tile per z.  The workgroups of a group stream the same weights
   // at the same time from different CUs of ONE XCD (gridDim.x * gridDim.y is a multiple of 8), so HBM sees each
   // byte once and the second reader is served by that XCD's L2; everything row-indexed is shifted by 16 rows.
-  if (gridDim.z > 1) {
+  // (a separate instantiation: the 16-row kernels stay exactly as they were — the extra prologue cost 2 % of the
+  // batch-8 step)
+  if constexpr (MZ) {
     const int z = blockIdx.z;
     p.A += (long)z * p.a_ktiles * 512;
     p.M = min(16, p.M - 16 * z);
@@ -1705,11 +1707,13 @@ int launch_g16(const GemmK& k, hipStream_t st) {
     if (spw > 1) {      // persistent multi-strip form, with or without split-K: A fragments loaded once per workgroup
       int gx = (k.nstrips + spw - 1) / spw;
       if (mz >= 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
-      launch_kernel(k_gemm16<NW, KPW, true>, dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
+      if (mz > 1) launch_kernel(k_gemm16<NW, KPW, true, true>, dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
+      else launch_kernel(k_gemm16<NW, KPW, true>, dim3(gx, sk), dim3(NW * 64), smem, st, k);
       return dia_check_launch("k_gemm16");
     }
   }
-  launch_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips, sk, mz), dim3(NW * 64), smem, st, k);
+  if (mz > 1) launch_kernel(k_gemm16<NW, KPW, false, true>, dim3(k.nstrips, sk, mz), dim3(NW * 64), smem, st, k);
+  else launch_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
   return dia_check_launch("k_gemm16");
 }
 
