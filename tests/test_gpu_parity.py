@@ -127,6 +127,34 @@ def test_batched_equals_single(mid):
         assert out[b].last_step == r.last_step
 
 
+@pytest.mark.parametrize("B", [10, 20, 40])
+def test_large_batches_vs_oracle(mid, B):
+    """batch 9-64 per GPU (17..128 rows: the one-m-tile GEMM kernel over 2..8 m-tiles, wo split four ways per m-tile):
+    every utterance of the batch == its own oracle run (three distinct runs, dealt round-robin)."""
+    cfg, sd, w = mid
+    mt = 24
+    seeds = [42, 7, 123]
+    runs = [oracle_run(cfg, sd, t, sd_, mt) for t, sd_ in zip(TEXTS, seeds)]
+    texts = [TEXTS[b % 3] for b in range(B)]
+    logits, res = teacher_forced(w, cfg, texts, [runs[b % 3][0].tokens for b in range(B)], [runs[b % 3][1] for b in range(B)], mt)
+    worst = 0.0
+    for b in range(B):
+        r = runs[b % 3][0]
+        for i in range(len(r.logits)):
+            worst = max(worst, float(np.abs(logits[i][b] - r.logits[i]).max()))
+        for i, p in enumerate(r.preds):
+            assert np.array_equal(res[b].preds[1 + i], p), (b, i)
+    print(f"batch {B} teacher-forced logits max-abs err {worst:.3e}")
+    assert worst <= LOGIT_TOL
+    # free running, graph replay: token buffers identical to the oracle's
+    ids = [encode_text(effective_text(t), cfg) for t in texts]
+    s = DecodeSession(w, ids, kv_dtype="f32", max_tokens=mt, seeds=[seeds[b % 3] for b in range(B)])
+    s.prefill(); s.run(use_graph=True, poll=8)
+    out = s.results(); s.close()
+    for b in range(B):
+        assert np.array_equal(out[b].tokens, runs[b % 3][0].tokens), b
+
+
 def test_encoder_and_cross_kv_mid(mid, golden):
     cfg, sd, w = mid
     g = golden("ref_mid.npz")
