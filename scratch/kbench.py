@@ -12,6 +12,8 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--prefetch", type=int, default=0)
 ap.add_argument("--same", type=int, default=0)
 ap.add_argument("--sk", type=int, default=0)
+ap.add_argument("--K", type=int, default=0, help="with --N: a custom RESID_EMIT shape instead of --shape")
+ap.add_argument("--N", type=int, default=0)
 ap.add_argument("--lend", type=int, default=0, help="lend split-K scratch (floats per strip and k-tile/8) so dia_gemm may pick k_gemm_blk32 at 17..32 rows")
 ap.add_argument("--sparse", type=float, default=0.0, help="fraction of zero weights -> zero-skipping stream")
 a = ap.parse_args()
@@ -20,6 +22,8 @@ K, N, epi = {"wi": (2048, 16384, hb.EPI_SWIGLU_EMIT), "wo": (8192, 2048, hb.EPI_
              "qkv": (2048, 3072, hb.EPI_SCALE_STORE), "logits": (2048, 9264, hb.EPI_SCALE_STORE),
              "eqkv": (1024, 3072, hb.EPI_SCALE_STORE), "eo": (1024, 1024, hb.EPI_RESID_EMIT), "ewi": (1024, 8192, hb.EPI_SWIGLU_EMIT), "ewo": (4096, 1024, hb.EPI_RESID_EMIT),
              "qkvp": (1024, 3072, hb.EPI_SCALE_STORE), "op": (1024, 2048, hb.EPI_RESID_EMIT), "wip": (1024, 8192, hb.EPI_SWIGLU_EMIT), "wop": (4096, 2048, hb.EPI_RESID_EMIT)}[a.shape]
+if a.K and a.N:
+    K, N, epi = a.K, a.N, hb.EPI_RESID_EMIT
 M = a.M
 mpad = (M + 15) // 16 * 16
 Ws = [torch.randint(-30000, 30000, (N // 16, K // 32, 64, 8), dtype=torch.int16, device=d).view(torch.bfloat16) for _ in range(18)]
