@@ -344,8 +344,21 @@ __device__ long long g_stamps[4096 * 8];
 #define STAMP(i) do {} while (0)
 #endif
 
-template <int NW, int KPW, int RS, bool MULTI>
+template <int NW, int KPW, int RS, bool MULTI, bool MZ = false>
 __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
+  // 5..16 rows (batch 3-8), short K, few strips: gridDim.z row groups of 4, each the 4-row kernel on rows 4z..4z+3 of
+  // the one m-tile (a row shift is a pointer shift in every layout involved).  Two workgroups fit a CU, so strips x
+  // groups <= 512 are all resident and the groups of a strip share its weights through L2 — against k_gemm16, whose
+  // one workgroup per strip pulls the whole 16-row image (192 KB at K = 2048) through one CU for 64 KB of weights.
+  if constexpr (MZ) {
+    const int r0 = 4 * blockIdx.z;
+    p.A += r0 * 8;
+    p.M = min(4, p.M - r0);
+    if (p.ssq_in) p.ssq_in += r0;
+    if (p.out) p.out += (long)r0 * p.ldo;
+    if (p.P) p.P += r0 * 8;
+    if (p.ssq_out) p.ssq_out += r0;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][64]
   float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * 64);   // [16][17]
@@ -1808,6 +1821,14 @@ int launch_small(const GemmK& k, hipStream_t st) {
   return dia_check_launch("k_gemv_small");
 }
 
+// row groups of 4 over gridDim.z (5..16 rows): 8 waves, K = 8 * KPW k-tiles, one strip per workgroup, no split-K
+template <int KPW>
+int launch_small_z(const GemmK& k, hipStream_t st) {
+  const size_t smem = small_smem(8, 8 * KPW, 4);
+  launch_kernel(k_gemv_small<8, KPW, 4, false, true>, dim3(k.nstrips, 1, k.mz), dim3(8 * 64), smem, st, k);
+  return dia_check_launch("k_gemv_small(z)");
+}
+
 template <int RS>
 int launch_small_rs(const GemmK& k, int nw, int sk, hipStream_t st, bool& handled) {
   handled = true;
@@ -1956,6 +1977,22 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
       bool handled = false;
       int rc = (rs == 2) ? launch_small_rs<2>(k, nw, sk, st, handled) : launch_small_rs<4>(k, nw, sk, st, handled);
       if (handled) return rc;
+    }
+  }
+  // 5..16 rows, K <= 2048, few strips: the 4-row kernel over row groups (k_gemv_small<..., MZ>), when every group of
+  // every strip is resident at once (two workgroups per CU).  DIA_DBG_ZSMALL = highest strips x groups.  OFF by
+  // default — measured slower in the step: o 9.2 -> 11.3 us at batch 8 (four groups), qkv 8.6 -> 11.2 at batch 3
+  // (two groups): the image traffic of k_gemm16 is not what bounds these launches, the workgroup count is.
+  if (mtiles == 1 && a->M > 4 && sk == 1 && !a->nw && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext) &&
+      (a->KT == 64 || a->KT == 32 || a->KT == 16)) {
+    int zmax = 0;
+    if (const char* e = getenv("DIA_DBG_ZSMALL")) zmax = atoi(e);
+    const int groups = (a->M + 3) / 4;
+    if (a->nstrips * groups <= zmax) {
+      k.mz = groups;
+      const int rc = a->KT == 64 ? launch_small_z<8>(k, st) : (a->KT == 32 ? launch_small_z<4>(k, st) : launch_small_z<2>(k, st));
+      k.mz = 0;
+      return rc;
     }
   }
   if (mtiles == 1 && a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext)) {

@@ -1,0 +1,38 @@
+"""bench.py's N > 1 path on a one-GPU box: two ranks launched the way the driver launches them
+(`python -m torch.distributed.run`), both on cuda:0 with gloo as the process group (rehearsal knob
+DIA_BENCH_SHARE_DEVICE=1 — everything but RCCL itself: rank-0 weight build, broadcast of the repacked tensors,
+per-rank sessions, barrier-bracketed timing, max over ranks, one JSON line from rank 0)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_two_ranks_share_device():
+    env = dict(os.environ, DIA_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "32", "--warmup", "4",
+           "--cpu-steps", "0", "--profile-steps", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 32 and d["warmup"] == 4 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["batch_per_gpu"] == 1
+    assert d["value"] > 0 and abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) <= 1e-2 * d["value"]     # whole-job frames/s
+    assert d["weights_bcast_s"] > 0
+    assert "cpu_baseline" not in d or d["cpu_baseline"] is None

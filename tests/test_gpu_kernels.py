@@ -293,6 +293,87 @@ def test_gemm_two_mtiles(M, monkeypatch):
     assert (outs[0][2][:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
 
 
+@pytest.mark.parametrize("M", [5, 8, 13, 16])
+def test_gemm_row_groups(M, monkeypatch):
+    """5..16 rows (batch 3-8), K <= 2048, strips x groups <= 512: the 4-row kernel over row groups of 4 (gridDim.z;
+    kernel-level experiment behind DIA_DBG_ZSMALL).
+    Every epilogue against float64, and bit for bit against the same kernel run on each 4-row slice alone."""
+    monkeypatch.setenv("DIA_DBG_ZSMALL", "512")      # opt-in: measured slower than k_gemm16 in the decode step
+    d = dev()
+    torch.manual_seed(300 + M)
+    L = hb.lib()
+
+    def args(A, M_, Wt, kt, ns, epi):
+        g = hb.GemmArgs()
+        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M_
+        g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, epi
+        return g
+
+    groups = [slice(r, min(r + 4, M)) for r in range(0, M, 4)]
+    for K, N in ((2048, 2048), (1024, 592), (512, 1024)):
+        x = torch.randn(M, K, device=d) * 2.0
+        gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
+        xd = x.double()
+        inv = torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+        W = bf16r(torch.randn(K, N, device=d) * 0.05)
+        Wt, kt, ns = lay.tile_weight(W)
+        # SCALE_STORE
+        outs = []
+        for rows in [slice(0, M)] + groups:
+            xs = x[rows]
+            A = lay.pack_planes(xs * gw)
+            out = torch.full((xs.shape[0], N), float("nan"), device=d)
+            sr = strip_ssq(xs, 16)
+            g = args(A, xs.shape[0], Wt, kt, ns, hb.EPI_SCALE_STORE)
+            g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(sr), K // 16, 1.0 / K, 1e-5, 16
+            g.out, g.ldo = hb.ptr(out), N
+            hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
+            torch.cuda.synchronize()
+            outs.append(out)
+        ref = ((xd * gw.double()) @ W.double()) * inv
+        assert (outs[0].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+        if ns * len(groups) <= 512:             # the row-group form ran: identical to its 4-row pieces
+            assert torch.equal(outs[0], torch.cat(outs[1:]))
+        # RESID_EMIT into D = N
+        x0 = torch.randn(M, N, device=d)
+        gn = bf16r(1.0 + 0.1 * torch.randn(N, device=d))
+        A2 = lay.pack_planes(x)
+        pkt = (N + 31) // 32
+        xr = x0.clone()
+        P = torch.zeros(3, 1, pkt, 64, 8, dtype=torch.bfloat16, device=d)
+        ssq = torch.zeros(ns, 16, device=d)
+        g = args(A2, M, Wt, kt, ns, hb.EPI_RESID_EMIT)
+        g.ssq_ld, g.out, g.ldo, g.gnext = 16, hb.ptr(xr), N, hb.ptr(gn)
+        g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), pkt, hb.ptr(ssq)
+        hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
+        torch.cuda.synchronize()
+        ref = x0.double() + xd @ W.double()
+        assert (xr.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        assert torch.equal(lay.unpack_planes(P, M, pkt * 32)[:, :N], xr * gn)
+        want = (xr.double() ** 2).reshape(M, N // 16, 16).sum(-1).T
+        assert (ssq[:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
+        assert (ssq[:, M:] == 0).all()
+    # SWIGLU_EMIT: K = 1024, F = 512 (64 strips)
+    K, F = 1024, 512
+    x = torch.randn(M, K, device=d) * 2.0
+    gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
+    xd = x.double()
+    wi = bf16r(torch.randn(K, 2, F, device=d) * 0.05)
+    Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi))
+    A = lay.pack_planes(x * gw)
+    ss = strip_ssq(x, 16)
+    P = torch.zeros(3, 1, F // 32, 64, 8, dtype=torch.bfloat16, device=d)
+    g = args(A, M, Wt, kt, ns, hb.EPI_SWIGLU_EMIT)
+    g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, 16
+    g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), F // 32
+    hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
+    torch.cuda.synchronize()
+    h = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
+    f = torch.einsum("mk,kgf->mgf", h, wi.double())
+    ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
+    assert (lay.unpack_planes(P, M, F).double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("M", [17, 23, 32, 40, 64, 100, 128])
 def test_gemm_paired_mtiles(M, monkeypatch):
     """17..64 rows (batch 9-32), default path: the one-m-tile kernel launched over all m-tiles (gridDim.z = 2..4).
