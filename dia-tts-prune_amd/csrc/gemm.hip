@@ -870,6 +870,10 @@ int launch_sparse(const GemmK& k, hipStream_t st) {
 // 5..16 rows (batch 3-8): one m-tile, A fragments held in registers for the workgroup's whole life
 // (each wave owns a fixed K range of KPW k-tiles = 12*KPW VGPRs) and reused for every strip the
 // workgroup walks; weight tiles double-buffered across strips like k_gemv_small.
+#ifndef DIA_Z_TEMPORAL
+#define DIA_Z_TEMPORAL 1
+#endif
+constexpr bool ZTEMPORAL = DIA_Z_TEMPORAL != 0;
 template <int NW, int KPW, bool MULTI, bool MZ = false>
 __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -901,7 +905,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
   auto load_strip = [&](bf16x8* b, int strip) {
     const bf16x8* Wt = Wl + (long)strip * p.KT * 64;
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) b[i] = DIA_WLOAD(Wt + (long)i * 64);
+    for (int i = 0; i < KPW; ++i) b[i] = (MZ && ZTEMPORAL) ? *(Wt + (long)i * 64) : DIA_WLOAD(Wt + (long)i * 64);   // z-form: the other m-tiles re-read these lines from L2
   };
   bf16x8 b0[KPW], b1[MULTI ? KPW : 1];
 
