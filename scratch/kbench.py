@@ -14,6 +14,7 @@ ap.add_argument("--same", type=int, default=0)
 ap.add_argument("--sk", type=int, default=0)
 ap.add_argument("--K", type=int, default=0, help="with --N: a custom RESID_EMIT shape instead of --shape")
 ap.add_argument("--N", type=int, default=0)
+ap.add_argument("--graph", type=int, default=0, help="capture 8 x 18 launches into a graph and replay it (per-launch time without the eager launch rate limit)")
 ap.add_argument("--lend", type=int, default=0, help="lend split-K scratch (floats per strip and k-tile/8) so dia_gemm may pick k_gemm_blk32 at 17..32 rows")
 ap.add_argument("--sparse", type=float, default=0.0, help="fraction of zero weights -> zero-skipping stream")
 a = ap.parse_args()
@@ -65,6 +66,21 @@ def launch(W):
 if a.same: Ws = Ws[:1] * 18
 for W in Ws: launch(W)
 torch.cuda.synchronize()
+if a.graph:
+    g_ = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g_, stream=st):
+            for _ in range(8):
+                for W in Ws: launch(W)
+        for _ in range(3): g_.replay()
+        st.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(a.reps): g_.replay()
+        e1.record(st); st.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (a.reps * 8 * 18)
+    print(f"{a.shape} M={M} nw={a.nw} graph: {us:.2f} us/launch, {K*N*2/us/1e3:.0f} GB/s")
+    sys.exit(0)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(st)
 for _ in range(a.reps):
