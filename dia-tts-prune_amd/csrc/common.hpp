@@ -27,6 +27,10 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 #pragma clang fp contract(off)
   return a * b;
 }
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
 #pragma clang fp contract(off)
   hi = (__bf16)v;

@@ -183,6 +183,55 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
   }
 }
 
+// M <= RS rows (k_gemv_small): RESID_EMIT and SWIGLU_EMIT with ONE element per thread (16*RS threads: row = tid / 16,
+// column = tid % 16) instead of eight per thread on half a wave — the 32-thread form spends 0.5 us of single-wave issue time
+// (8 three-way bf16 splits per thread) at the very end of every o / co / wo / wi launch.  Results are bit-identical
+// to run_epilogue: the strip's sum of squares is accumulated in the same order (columns 0..7 of each half in
+// sequence, rounded squares and plain adds, then half 0 + half 1) through lane shifts.
+template <int RS>
+__device__ __forceinline__ void run_epilogue_rows(const GemmK& p, const float* tile, const float* inv_s, int tid, int strip,
+                                                  float xpre1, float gpre1) {
+  const int m = tid >> 4, c = tid & 15;
+  const bool live = m < p.M;
+  if (p.epi == DIA_EPI_RESID_EMIT) {
+    const int n = strip * 16 + c;
+    const float v = xpre1 + tile[m * 17 + c];
+    if (live) p.out[(long)m * p.ldo + n] = v;
+    const float sq = mul_rn(v, v);      // (the 32-thread form squares with packed multiplies and adds in sequence: no FMA)
+    float acc = sq;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      const float t = __shfl_up(acc, 1, 64);
+      if ((c & 7) == j) acc = add_rn(t, sq);
+    }
+    const int lane = tid & 63;
+    const float h0 = __shfl(acc, (lane & ~15) | 7, 64), h1 = __shfl(acc, (lane & ~15) | 15, 64);
+    if (live && c == 0) p.ssq_out[(long)strip * p.ssq_ld + m] = h0 + h1;
+    const float vg = mul_rn(v, gpre1);
+    int cc = n;
+    if (p.cmap) cc = p.cmap[n];
+    if (live && cc >= 0) {
+      __bf16 a, b, d;
+      split3(vg, a, b, d);
+      const long off = plane_frag_off(m, cc & ~7, p.p_ktiles) + (cc & 7);
+      p.P[off] = *reinterpret_cast<bf16_raw*>(&a);
+      p.P[p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&b);
+      p.P[2 * p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&d);
+    }
+  } else {  // DIA_EPI_SWIGLU_EMIT: columns 0..7 gate, 8..15 up
+    if (!live || c >= 8) return;
+    const float inv = inv_s[m];
+    const float g = tile[m * 17 + c] * inv, u = tile[m * 17 + 8 + c] * inv;
+    const float v = (g / (1.0f + expf(-g))) * u;
+    __bf16 a, b, d;
+    split3(v, a, b, d);
+    const long off = plane_frag_off(m, strip * 8, p.p_ktiles) + c;
+    p.P[off] = *reinterpret_cast<bf16_raw*>(&a);
+    p.P[p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&b);
+    p.P[2 * p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&d);
+  }
+}
+
 // split-K partials -> LDS -> fixed-order sum -> 16x16 tile(s) in LDS
 template <int MT, int NW, bool RAW = false>
 __device__ __forceinline__ void reduce_to_tile(const f32x4* acc, f32x4* red, float* tile, int tid, int lane, int w) {
@@ -415,17 +464,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
   }
   // (3) residual row + next norm weight of the first strip (RESID_EMIT only)
   const bool resid = p.epi == DIA_EPI_RESID_EMIT;
+  const bool rows_epi = resid || p.epi == DIA_EPI_SWIGLU_EMIT;      // one element per thread (run_epilogue_rows)
+  const bool r_thread = tid < 16 * RS;
+  float xpre1 = 0.f, gpre1 = 1.f;
   auto load_resid = [&](int strip) {
-    const int n0 = strip * 16 + half * 8;
-    const float* o = p.out + (long)(live ? m : 0) * p.ldo + n0;
-    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
-    xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
-    xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
-    const float4 ga = *reinterpret_cast<const float4*>(p.gnext + n0), gb = *reinterpret_cast<const float4*>(p.gnext + n0 + 4);
-    gpre[0] = ga.x; gpre[1] = ga.y; gpre[2] = ga.z; gpre[3] = ga.w;
-    gpre[4] = gb.x; gpre[5] = gb.y; gpre[6] = gb.z; gpre[7] = gb.w;
+    const int r_m = tid >> 4, n = strip * 16 + (tid & 15);
+    xpre1 = p.out[(long)(r_m < p.M ? r_m : 0) * p.ldo + n];
+    gpre1 = p.gnext[n];
   };
-  if (resid && e_thread) load_resid(blockIdx.x);
+  if (resid && r_thread) load_resid(blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
   load_strip(b0, blockIdx.x);                       // the HBM stream starts here
   __builtin_amdgcn_sched_barrier(0);
@@ -464,10 +511,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
     reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
     STAMP(4);
     if (!MULTI) { if (!splitk_combine(p, tile, strip, tid, &sk_flag)) return; }
-    if (e_thread) {
+    if (rows_epi) {
+      if (r_thread) {
+        run_epilogue_rows<RS>(p, tile, inv_s, tid, strip, xpre1, gpre1);
+        if (MULTI && next < p.nstrips && resid) load_resid(next);      // residual operands of the next strip
+      }
+    } else if (e_thread) {
       const int n0 = strip * 16 + half * 8;
       run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
-      if (MULTI && next < p.nstrips && resid) load_resid(next);      // residual operands of the next strip
     }
   };
   if constexpr (MULTI) {
@@ -973,6 +1024,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], bc[i], acc[0], 0, 0, 0);
     reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
     const bool last_slice = splitk_combine(p, tile, strip, tid, &sk_flag);      // workgroup-uniform; true without split-K
+    // (one element per thread as in k_gemv_small was measured here too: bit-identical, 1.3 % SLOWER at batch 8 - 768
+    // two-byte plane stores per tile instead of 96 sixteen-byte ones)
     if (e_thread) {
       const int n0 = strip * 16 + half * 8;
       if (last_slice) run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
