@@ -61,6 +61,45 @@ __global__ void k_gemvlike(const u4* w, const u4* a_in, u4* a_out, float* out, i
   } else if (s == 0x12345678u) out[blockIdx.x] = 1.f;
 }
 
+// (h) again with the real kernel's resource footprint: dynamic LDS and a forced VGPR allocation
+template <int F>
+__global__ __attribute__((amdgpu_num_vgpr(128))) void k_gemvlike_fat(const u4* w, const u4* a_in, u4* a_out, float* out, int per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  u4* As = reinterpret_cast<u4*>(dyn);
+  float (*red)[64] = reinterpret_cast<float (*)[64]>(dyn + 1536 * 16);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  u4 av[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) av[i] = a_in[tid + 512 * i];
+  const u4* base = w + (size_t)blockIdx.x * per_wg + tid;
+  u4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(base + i * 512);
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) As[tid + 512 * i] = av[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const u4 t = As[(tid * 7 + 512 * i + 13) % 1536]; s += t.x ^ t.w; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+  red[wv][lane] = (float)s;
+  __syncthreads();
+  if (tid < 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += red[k][tid];
+    red[0][tid] = a;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const float x = red[0][tid] + red[0][tid + 32];
+    const unsigned xb = __float_as_uint(x) | 1u;
+    const u4 o = {xb, xb + 1, xb + 2, xb + 3};
+    if (tid < 12) a_out[(blockIdx.x % 128) * 12 + tid] = o;
+  }
+}
+
 template <typename F>
 int run(const char* name, hipStream_t st, int n, F launch) {
   hipGraph_t g; hipGraphExec_t ge;
@@ -100,6 +139,8 @@ int main() {
   RUN("(g) (e) + (f)", 3, 128, a0, a1);
   RUN("(h) (g), operand WRITTEN by the previous launch (ping-pong)", 7, 128, (i & 1) ? a1 : a0, (i & 1) ? a0 : a1);
   RUN("(i) (h) without the weight stream", 15, 128, (i & 1) ? a1 : a0, (i & 1) ? a0 : a1);
+  if (run("(k) (h) with 34 KB of dynamic LDS and 128 VGPRs allocated", st, N, [&](int i) { hipLaunchKernelGGL(k_gemvlike_fat<7>, dim3(128), dim3(512), 34816, st, wb(i), (i & 1) ? a1 : a0, (i & 1) ? a0 : a1, out, 4096); })) return 1;
+  if (run("(l) (k) with 60 KB of dynamic LDS", st, N, [&](int i) { hipLaunchKernelGGL(k_gemvlike_fat<7>, dim3(128), dim3(512), 61440, st, wb(i), (i & 1) ? a1 : a0, (i & 1) ? a0 : a1, out, 4096); })) return 1;
   // (j): 256 workgroups read 16 MB per launch — 32 distinct 16 MB windows of the same 512 MB buffer
   if (run("(j) (h) with 256 workgroups, 16 MB", st, N, [&](int i) { hipLaunchKernelGGL(k_gemvlike<7>, dim3(256), dim3(512), 0, st, big + (size_t)(i % 32) * ((16u << 20) / 16), (i & 1) ? a1 : a0, (i & 1) ? a0 : a1, out, 4096); })) return 1;
   return 0;
