@@ -48,6 +48,10 @@ void launch_kernel(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream_t st
   else hipLaunchKernelGGL(kern, grid, block, smem, st, arg);
 }
 
+struct GemmK;
+template <typename Kern>
+void launch_small_kernel(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream_t st, const GemmK& k);
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // plain vector: HIP's uint4 struct defeats SROA in register arrays
 
 struct GemmK {
@@ -68,6 +72,13 @@ struct GemmK {
   const unsigned char* sp_blocks; const unsigned int* sp_toff;   // zero-skipping weight stream (k_gemv_sparse)
   int mz;                                  // host side only: m-tiles a k_gemm16 launch covers through gridDim.z (0/1 = one)
 };
+
+template <typename Kern>
+void launch_small_kernel(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream_t st, const GemmK& k) {
+  if (g_ev_start) hipExtLaunchKernelGGL(kern, grid, block, smem, st, g_ev_start, g_ev_stop, 0, k.A, k.a_plane_stride, k.W, k.KT, k.M, k.epi,
+                                        k.nstrips, k.out, k.ldo, k.gnext, k);
+  else hipLaunchKernelGGL(kern, grid, block, smem, st, k.A, k.a_plane_stride, k.W, k.KT, k.M, k.epi, k.nstrips, k.out, k.ldo, k.gnext, k);
+}
 
 __device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v) {
   if (dtype == DIA_KV_F32) reinterpret_cast<float*>(base)[idx] = v;
@@ -393,8 +404,15 @@ __device__ long long g_stamps[4096 * 8];
 #define STAMP(i) do {} while (0)
 #endif
 
+// The first ten arguments repeat fields of p: they fill the first 64 bytes of the argument block, which the command
+// processor hands over in SGPRs at wave launch (kernarg preload, -mllvm -amdgpu-kernarg-preload-count=16) — the operand
+// and weight loads of the prologue then need no scalar load from the argument block, whose lines every CU of the grid
+// otherwise requests at the same moment (in-kernel stamps: 0.8 us from the start of a wave to its first weight load).
 template <int NW, int KPW, int RS, bool MULTI, bool MZ = false>
-__global__ __launch_bounds__(NW * 64) void k_gemv_small(GemmK p) {
+__global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
+                                                        int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
+  p.A = a_A; p.a_plane_stride = a_aps; p.W = a_W; p.KT = a_KT; p.M = a_M; p.epi = a_epi; p.nstrips = a_nstrips;
+  p.out = a_out; p.ldo = a_ldo; p.gnext = a_gnext;
   // 5..16 rows (batch 3-8), short K, few strips: gridDim.z row groups of 4, each the 4-row kernel on rows 4z..4z+3 of
   // the one m-tile (a row shift is a pointer shift in every layout involved).  Two workgroups fit a CU, so strips x
   // groups <= 512 are all resident and the groups of a strip share its weights through L2 — against k_gemm16, whose
@@ -930,7 +948,11 @@ int launch_sparse(const GemmK& k, hipStream_t st) {
 #endif
 constexpr bool ZTEMPORAL = DIA_Z_TEMPORAL != 0;
 template <int NW, int KPW, bool MULTI, bool MZ = false>
-__global__ __launch_bounds__(NW * 64) void k_gemm16(GemmK p) {
+__global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
+                                                    int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
+  // (leading arguments = fields of p, preloaded into SGPRs: see k_gemv_small)
+  p.A = a_A; p.a_plane_stride = a_aps; p.W = a_W; p.KT = a_KT; p.M = a_M; p.epi = a_epi; p.nstrips = a_nstrips;
+  p.out = a_out; p.ldo = a_ldo; p.gnext = a_gnext;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][64]
   float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * 64);   // [16][17]
@@ -1781,13 +1803,13 @@ int launch_g16(const GemmK& k, hipStream_t st) {
     if (spw > 1) {      // persistent multi-strip form, with or without split-K: A fragments loaded once per workgroup
       int gx = (k.nstrips + spw - 1) / spw;
       if (mz >= 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
-      if (mz > 1) launch_kernel(k_gemm16<NW, KPW, true, true>, dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
-      else launch_kernel(k_gemm16<NW, KPW, true>, dim3(gx, sk), dim3(NW * 64), smem, st, k);
+      if (mz > 1) launch_small_kernel(k_gemm16<NW, KPW, true, true>, dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
+      else launch_small_kernel(k_gemm16<NW, KPW, true>, dim3(gx, sk), dim3(NW * 64), smem, st, k);
       return dia_check_launch("k_gemm16");
     }
   }
-  if (mz > 1) launch_kernel(k_gemm16<NW, KPW, false, true>, dim3(k.nstrips, sk, mz), dim3(NW * 64), smem, st, k);
-  else launch_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
+  if (mz > 1) launch_small_kernel(k_gemm16<NW, KPW, false, true>, dim3(k.nstrips, sk, mz), dim3(NW * 64), smem, st, k);
+  else launch_small_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
   return dia_check_launch("k_gemm16");
 }
 
@@ -1868,16 +1890,16 @@ int launch_small(const GemmK& k, hipStream_t st) {
   const int grid = (k.nstrips + spw - 1) / spw;
   const int sk = k.KT / (NW * KPW);          // cross-workgroup split-K factor (1 = none)
   if (sk > 1) {
-    launch_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
+    launch_small_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
     return dia_check_launch("k_gemv_small");
   }
   if (spw > 1) {
     if constexpr (KPW <= 16 && !(NW == 16 && KPW > 4))
-      launch_kernel(k_gemv_small<NW, KPW, RS, true>, dim3(grid), dim3(NW * 64), smem, st, k);
+      launch_small_kernel(k_gemv_small<NW, KPW, RS, true>, dim3(grid), dim3(NW * 64), smem, st, k);
     else
-      launch_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+      launch_small_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips), dim3(NW * 64), smem, st, k);
   } else {
-    launch_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+    launch_small_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips), dim3(NW * 64), smem, st, k);
   }
   return dia_check_launch("k_gemv_small");
 }
@@ -1886,7 +1908,7 @@ int launch_small(const GemmK& k, hipStream_t st) {
 template <int KPW>
 int launch_small_z(const GemmK& k, hipStream_t st) {
   const size_t smem = small_smem(8, 8 * KPW, 4);
-  launch_kernel(k_gemv_small<8, KPW, 4, false, true>, dim3(k.nstrips, 1, k.mz), dim3(8 * 64), smem, st, k);
+  launch_small_kernel(k_gemv_small<8, KPW, 4, false, true>, dim3(k.nstrips, 1, k.mz), dim3(8 * 64), smem, st, k);
   return dia_check_launch("k_gemv_small(z)");
 }
 

@@ -100,6 +100,47 @@ __global__ __attribute__((amdgpu_num_vgpr(128))) void k_gemvlike_fat(const u4* w
   }
 }
 
+// (h) once more with wall-clock stamps: when does each workgroup start, issue its stream, finish?
+__global__ void k_gemvlike_stamped(const u4* w, const u4* a_in, u4* a_out, float* out, int per_wg, long long* stamps) {
+  __shared__ u4 As[1536];
+  __shared__ float red[8][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) stamps[blockIdx.x * 4 + 0] = wall_clock64();
+  u4 av[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) av[i] = a_in[tid + 512 * i];
+  const u4* base = w + (size_t)blockIdx.x * per_wg + tid;
+  u4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(base + i * 512);
+  if (tid == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) As[tid + 512 * i] = av[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const u4 t = As[(tid * 7 + 512 * i + 13) % 1536]; s += t.x ^ t.w; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+  red[wv][lane] = (float)s;
+  __syncthreads();
+  if (tid == 0) stamps[blockIdx.x * 4 + 2] = wall_clock64();
+  if (tid < 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += red[k][tid];
+    red[0][tid] = a;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const float x = red[0][tid] + red[0][tid + 32];
+    const unsigned xb = __float_as_uint(x) | 1u;
+    const u4 o = {xb, xb + 1, xb + 2, xb + 3};
+    if (tid < 12) a_out[(blockIdx.x % 128) * 12 + tid] = o;
+  }
+  if (tid == 0) stamps[blockIdx.x * 4 + 3] = wall_clock64();
+}
+
 template <typename F>
 int run(const char* name, hipStream_t st, int n, F launch) {
   hipGraph_t g; hipGraphExec_t ge;
@@ -143,5 +184,20 @@ int main() {
   if (run("(l) (k) with 60 KB of dynamic LDS", st, N, [&](int i) { hipLaunchKernelGGL(k_gemvlike_fat<7>, dim3(128), dim3(512), 61440, st, wb(i), (i & 1) ? a1 : a0, (i & 1) ? a0 : a1, out, 4096); })) return 1;
   // (j): 256 workgroups read 16 MB per launch — 32 distinct 16 MB windows of the same 512 MB buffer
   if (run("(j) (h) with 256 workgroups, 16 MB", st, N, [&](int i) { hipLaunchKernelGGL(k_gemvlike<7>, dim3(256), dim3(512), 0, st, big + (size_t)(i % 32) * ((16u << 20) / 16), (i & 1) ? a1 : a0, (i & 1) ? a0 : a1, out, 4096); })) return 1;
+  {   // stamped skeleton: a few back-to-back launches, the last one's timeline (100 MHz clock)
+    long long* st_d; CK(hipMalloc(&st_d, 128 * 4 * sizeof(long long)));
+    for (int i = 0; i < 6; ++i) hipLaunchKernelGGL(k_gemvlike_stamped, dim3(128), dim3(512), 0, st, wb(i), (i & 1) ? a1 : a0, (i & 1) ? a0 : a1, out, 4096, st_d);
+    CK(hipStreamSynchronize(st));
+    std::vector<long long> h(128 * 4);
+    CK(hipMemcpy(h.data(), st_d, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    long long t0 = h[0];
+    for (int b = 0; b < 128; ++b) t0 = h[b * 4] < t0 ? h[b * 4] : t0;
+    const char* names[4] = {"start", "stream issued", "stream consumed", "end"};
+    for (int k = 0; k < 4; ++k) {
+      double mn = 1e9, mx = 0, sum = 0;
+      for (int b = 0; b < 128; ++b) { const double us = (h[b * 4 + k] - t0) / 100.0; mn = us < mn ? us : mn; mx = us > mx ? us : mx; sum += us; }
+      printf("    skeleton workgroups: %-16s min %5.2f  mean %5.2f  max %5.2f us\n", names[k], mn, sum / 128, mx);
+    }
+  }
   return 0;
 }
