@@ -26,7 +26,6 @@ import numpy as np
 import torch
 
 PROMPT = "[S1] Dia is an open weights text to dialogue model. [S2] You get full control over scripts and voices."
-SENT = "[S1] Dia is an open weights text to dialogue model. [S2] You get full control over scripts and voices. "
 MIXED_L = [32, 64, 96, 128, 192, 256, 384, 512]
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 FRAME_RATE = 44100.0 / 512.0   # 86.13 frames per second of audio
@@ -41,14 +40,12 @@ def cpu_threads() -> int:
     return max(1, min(16, n))     # a 1-GPU job owns a 16-core share of the host
 
 
-def texts_for(batch: int):
+def texts_for(batch: int, cfg):
+    """batch 1: the README prompt (98 byte tokens); else SURVEY.md §8d's mixed lengths 32..512 (sum 1664 per 8)"""
     if batch == 1:
         return [PROMPT]
-    out = []
-    for i in range(batch):
-        L = MIXED_L[i % len(MIXED_L)]
-        out.append((SENT * 8)[: L - 5])          # effective_text appends " [Sx]" (5 bytes)
-    return out
+    from dia_hip.tokens import synthetic_text
+    return [synthetic_text(MIXED_L[i % len(MIXED_L)], cfg) for i in range(batch)]
 
 
 def main():
@@ -119,7 +116,7 @@ def main():
         bcast_s = time.time() - tb
     load_s = time.time() - t0
 
-    texts = texts_for(args.batch)
+    texts = texts_for(args.batch, cfg)
     ids = [encode_text(effective_text(t), cfg) for t in texts]
     seeds = [42 + 1000 * rank + i for i in range(args.batch)]
     sess = DecodeSession(w, ids, kv_dtype=args.kv, max_tokens=max_tokens, seeds=seeds, ignore_eos=True)

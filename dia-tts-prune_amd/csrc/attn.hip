@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
+#include "tuning.hpp"
 #include <cstdlib>
 
 namespace {
@@ -173,7 +174,14 @@ __global__ __launch_bounds__(NT) void k_attn(AttnK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kvh = blockIdx.x, chunk = blockIdx.z;
-  // mode decode, branch-free (cur/len are never null here: dia_attn substitutes a readable dummy):
+  // mode decode, branch-free (cur/len are never null here: dia_attn substitutes a readable dummy).
+  // History (round 1, gpurun_out/t5-t8.log): while this tail was being factored out into attn_finish, an UNCOMMITTED
+  // intermediate of the then branchy decode (`int qrow, kvrow, pos, nkeys, slot = -1, head_row;` assigned per mode
+  // branch) left a row index unset on the ENC path.  test_attn_encoder_mode_and_kv_prep faulted on a non-null heap
+  // address just past an allocation (an out-of-range row into q / P, not a null cur / len), the next build computed
+  // wrong values without faulting (max error 1.74), and the committed states on either side (665b5d6, 8e4f8ca) pass:
+  // a source-level slip of the work in progress, not a compiler problem.  Since then the decode is a set of selects,
+  // every variable is const-initialised, and dia_attn checks n_rows / enc_len / kv_cap / rope_rows on the host.
   //   SELF  row = grid y, kv row = row, position = cur[row/2], keys = cur, new slot = cur-1
   //   CROSS utterance b = grid y, row = 2b+1 (cond), kv row = b, position = cur[b], keys = len[b]
   //   ENC   row = grid y, kv row = 0, position = row, keys = enc_len
@@ -831,12 +839,20 @@ extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
   if (!a || !a->q || !a->kc || !a->vc || !a->P || !a->cos_t || !a->sin_t) return dia_fail(DIA_E_ARG, "dia_attn: null argument");
   if (a->n_rows <= 0 || a->n_kv_heads <= 0) return dia_fail(DIA_E_ARG, "dia_attn: empty problem");
   if (a->p_plane_stride % 8 != 0) return dia_fail(DIA_E_ARG, "dia_attn: plane stride must be a multiple of 8");
+  // every index the kernels derive from the launch shape is checked here against what the caller states about its
+  // buffers: ENC reads q row / RoPE row / emits plane row blockIdx.y for blockIdx.y < n_rows, and keys 0..enc_len-1 of
+  // a kv_cap-row scratch cache; SELF reads RoPE row cur <= kv_cap
+  if (a->mode == DIA_ATTN_ENC && (a->n_rows != a->enc_len || a->enc_len <= 0 || a->enc_len > a->kv_cap))
+    return dia_fail(DIA_E_ARG, "dia_attn: ENC needs n_rows == enc_len and 0 < enc_len <= kv_cap");
+  if (a->rope_rows > 0 && ((a->mode == DIA_ATTN_ENC && a->enc_len > a->rope_rows) || (a->mode == DIA_ATTN_SELF && a->kv_cap + 1 > a->rope_rows)))
+    return dia_fail(DIA_E_ARG, "dia_attn: RoPE tables shorter than the positions this launch can reach");
+  if (a->kv_cap <= 0) return dia_fail(DIA_E_ARG, "dia_attn: kv_cap must be positive");
   const int cap_keys = a->mode == DIA_ATTN_ENC ? a->enc_len : a->kv_cap;
   const int cap_chunks = (cap_keys + CHUNK - 1) / CHUNK;
   // key-split factor: ~2 workgroups of 4 waves per CU, never more than one split per 128 keys of
   // capacity (the scratch sizing granule), and each split at least one 64-key unit
   int max_chunks = (512 + a->n_rows * a->n_kv_heads - 1) / (a->n_rows * a->n_kv_heads);
-  if (const char* e = getenv("DIA_DBG_NZ")) { if (atoi(e) > 0) max_chunks = atoi(e); }
+  if (dia_tune(DIA_TUNE_ATTN_NZ) > 0) max_chunks = dia_tune(DIA_TUNE_ATTN_NZ);
   if (max_chunks > cap_chunks) max_chunks = cap_chunks;
   if (max_chunks < 1) max_chunks = 1;
   if (max_chunks > 1 && (!a->scratch || !a->tickets)) return dia_fail(DIA_E_ARG, "dia_attn: more than 128 keys possible: scratch and tickets are required");
@@ -848,7 +864,7 @@ extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
   k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles;
   k.head_map = a->head_map; k.v_blocked = a->v_blocked;
   k.gpw = 1;
-  if (const char* e = getenv(a->mode == DIA_ATTN_CROSS ? "DIA_DBG_GPW_CROSS" : "DIA_DBG_GPW")) { if (atoi(e) > 0) k.gpw = atoi(e); }
+  { const int g = dia_tune(a->mode == DIA_ATTN_CROSS ? DIA_TUNE_ATTN_GPW_CROSS : DIA_TUNE_ATTN_GPW); if (g > 0) k.gpw = g; }
   // the kernels decode the mode branch-free and load cur[]/len[] unconditionally (index 0 when the mode
   // does not use them): never hand them a null pointer
   if (!k.cur) k.cur = reinterpret_cast<const int*>(a->cos_t);

@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
+#include "tuning.hpp"
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
@@ -50,6 +51,7 @@ static inline void mark(dia_engine* e, int i) {
 int dia_kernels_init_once() {
   static int rc = -100;
   if (rc == -100) {
+    dia_tuning_init_from_env();
     rc = dia_attn_init();
     if (rc == DIA_OK) rc = dia_sample_init();
     if (rc == DIA_OK) rc = dia_gemm_init();
@@ -89,7 +91,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     a.mode = DIA_ATTN_SELF; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.kv_heads; a.group = d.q_heads / d.kv_heads;
     a.n_rows = R; a.kv_cap = d.T; a.q = d.qkv; a.ldq = nqkv; a.q_off = 0; a.k_off = d.q_heads * 128;
     a.v_off = (d.q_heads + d.kv_heads) * 128; a.kc = L.k_self; a.vc = L.v_self; a.cur = d.sample.cur;
-    a.head_map = L.hmap_self; a.v_blocked = d.v_blocked;
+    a.head_map = L.hmap_self; a.v_blocked = d.v_blocked; a.rope_rows = d.T + 1;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
     a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
     if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
@@ -143,23 +145,23 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     // per strip, which also brings the per-wave K range down to what k_gemm16 keeps in registers (23.2 ->
     // 18.4 us in the step at batch 8).  Shapes without a split kernel fall back to one workgroup per strip.
     int wo_sk = (R <= 4 && L.kt_wo % 2 == 0) ? 2 : ((R <= 16 && L.kt_wo % 4 == 0) ? 4 : 1);
-    if (const char* ev = getenv("DIA_DBG_WO_SK")) wo_sk = atoi(ev) >= 1 && atoi(ev) <= 4 ? atoi(ev) : wo_sk;
+    if (dia_tune(DIA_TUNE_WO_SK) >= 1 && dia_tune(DIA_TUNE_WO_SK) <= 4) wo_sk = dia_tune(DIA_TUNE_WO_SK);
     g.sk = wo_sk; g.sk_scratch = wo_sk > 1 ? d.sk_scratch : nullptr; g.sk_tickets = wo_sk > 1 ? d.sk_tickets : nullptr;
     bool wo_pair = false;
     if (R > 16 && R <= 128) {     // 2..8 m-tiles: split-K 4 over every m-tile (k_gemm16 with gridDim.z) when the scratch covers
       g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets;    // it, else dia_gemm splits K by itself (two m-tiles: k_gemm32)
       g.sk_scratch_floats = d.sk_scratch_floats > 0 ? d.sk_scratch_floats : (int64_t)(d.D / 16) * 4 * 512;
       wo_pair = L.kt_wo % 4 == 0 && g.sk_scratch_floats >= (int64_t)((R + 15) / 16) * L.ns_wo * 4 * 256 &&
-                !(getenv("DIA_DBG_WO_PAIR") && atoi(getenv("DIA_DBG_WO_PAIR")) == 0);
+                dia_tune(DIA_TUNE_WO_PAIR) != 0;
       g.sk = wo_pair ? 4 : 1;
     }
-    if (const char* ev = getenv("DIA_DBG_WO_NW")) g.nw = atoi(ev);
-    if (const char* ev = getenv("DIA_DBG_WO_SPW")) g.spw = atoi(ev);
+    if (dia_tune(DIA_TUNE_WO_NW) > 0) g.nw = dia_tune(DIA_TUNE_WO_NW);
+    if (dia_tune(DIA_TUNE_WO_SPW) > 0) g.spw = dia_tune(DIA_TUNE_WO_SPW);
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D;
     g.gnext = (l + 1 < d.n_layer) ? e->layers[l + 1].g_sa : d.g_final;
     g.cmap = L.cmap_next;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
-    // opt-in (DIA_MLP_FUSE=1), batch 1: wi and wo in one persistent launch (dia_mlp_fused).  Anything it refuses
+    // opt-in (tuning knob mlp_fuse, EXPERIMENTS=1 builds), batch 1: wi and wo in one persistent launch (dia_mlp_fused).  Anything it refuses
     // (rows, shapes, CU count) takes the two launches below.
     if (e->mlp_fused != 0 && R <= 2 && d.mlp_barrier && !L.cmap_mlp) {
       dia_gemm_args go = g;
@@ -214,7 +216,7 @@ extern "C" int dia_engine_create(const dia_engine_desc* d, void* stream, dia_eng
   // measured: 37 us fused vs 27 us as two launches (batch 1, full size) — the write-through stores of the hidden
   // planes are acknowledged late under the weight stream (up to 10 us), the barrier and the coherent re-read add
   // 3.5 us each.  Kept as an opt-in experiment.
-  e->mlp_fused = getenv("DIA_MLP_FUSE") ? -1 : 0;
+  e->mlp_fused = dia_tune(DIA_TUNE_MLP_FUSE) > 0 ? -1 : 0;
   *out = e;
   return DIA_OK;
 }

@@ -14,13 +14,13 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIA_HIP_LIB") or os.path.join(_HERE, "libdia_hip.so")   # override: experiments only
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 KV_F32, KV_BF16 = 0, 1
 EPI_SCALE_STORE, EPI_RESID_EMIT, EPI_SWIGLU_EMIT, EPI_CROSSKV = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
 
 EXPORTS = (
-    "dia_last_error", "dia_abi_version", "dia_device_count", "dia_gemm", "dia_gemm_timed", "dia_mlp_fused", "dia_mlp_fused_timed", "dia_engine_mlp_fused", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep", "dia_enc_attn", "dia_dec_prefill_embed", "dia_dec_prefill_kv", "dia_dec_prefill_attn",
+    "dia_last_error", "dia_abi_version", "dia_device_count", "dia_set_tuning", "dia_get_tuning", "dia_has_experiments", "dia_gemm", "dia_gemm_timed", "dia_mlp_fused", "dia_mlp_fused_timed", "dia_engine_mlp_fused", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep", "dia_enc_attn", "dia_dec_prefill_embed", "dia_dec_prefill_kv", "dia_dec_prefill_attn",
     "dia_embed_text", "dia_embed_tokens", "dia_sample", "dia_prefetch", "dia_engine_create", "dia_engine_destroy",
     "dia_engine_decode", "dia_engine_set_prefetch", "dia_engine_step_logits_only", "dia_engine_profile_step", "dia_engine_launches_per_step",
 )
@@ -53,7 +53,7 @@ class AttnArgs(C.Structure):
         ("n_rows", C.c_int32), ("kv_cap", C.c_int32),
         ("q", C.c_void_p), ("ldq", C.c_int32), ("q_off", C.c_int32), ("k_off", C.c_int32), ("v_off", C.c_int32),
         ("kc", C.c_void_p), ("vc", C.c_void_p), ("cur", C.c_void_p), ("len", C.c_void_p),
-        ("enc_len", C.c_int32), ("_pad0", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
+        ("enc_len", C.c_int32), ("rope_rows", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("_pad1", C.c_int32),
         ("scratch", C.c_void_p), ("tickets", C.c_void_p), ("head_map", C.c_void_p),
         ("v_blocked", C.c_int32), ("_pad2", C.c_int32),
@@ -167,6 +167,9 @@ def lib() -> C.CDLL:
     L.dia_abi_version.restype = C.c_int
     if L.dia_abi_version() != ABI_VERSION:
         raise DiaHipError(f"ABI mismatch: library {L.dia_abi_version()} vs binding {ABI_VERSION}")
+    L.dia_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    L.dia_get_tuning.argtypes = [C.c_char_p]
+    L.dia_has_experiments.restype = C.c_int
     L.dia_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
     L.dia_gemm_timed.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.POINTER(C.c_float)]
     L.dia_mlp_fused.argtypes = [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.c_void_p, C.c_void_p]
@@ -193,6 +196,15 @@ def lib() -> C.CDLL:
     L.dia_engine_profile_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     _lib = L
     return L
+
+
+def set_tuning(name: str, value: int) -> None:
+    """launch-heuristic override (csrc/tuning.hpp); value < 0 clears it"""
+    check(lib().dia_set_tuning(name.encode(), int(value)), f"dia_set_tuning({name})")
+
+
+def has_experiments() -> bool:
+    return bool(lib().dia_has_experiments())
 
 
 def check(rc: int, what: str = "") -> None:

@@ -215,9 +215,15 @@ class DecodeSession:
                  top_p: float = 0.95, top_k: int = 35, seeds: Optional[Sequence[Optional[int]]] = None,
                  noise: Optional[torch.Tensor] = None, ignore_eos: bool = False,
                  teacher_tokens: Optional[Sequence[np.ndarray]] = None, stream: Optional[torch.cuda.Stream] = None,
-                 s_cap: Optional[int] = None, audio_prompts: Optional[Sequence[Optional[np.ndarray]]] = None):
+                 s_cap: Optional[int] = None, audio_prompts: Optional[Sequence[Optional[np.ndarray]]] = None,
+                 prompt_prefill: str = "auto", attention: str = "auto"):
         """audio_prompts: per utterance None or int codes [Tp, C] (reference model.py:311-353).  The prompt
-        rows are replayed through the decode step before sampling starts (semantics: oracle.generate)."""
+        rows are replayed through the decode step before sampling starts (semantics: oracle.generate), or — with
+        bf16 caches — prefilled as one packed MFMA batch; prompt_prefill="replay" forces the replay.
+        attention="valu" keeps bf16 V caches row-major and runs the VALU attention kernel (comparison runs)."""
+        if prompt_prefill not in ("auto", "replay") or attention not in ("auto", "valu"):
+            raise ValueError("prompt_prefill must be 'auto' or 'replay', attention 'auto' or 'valu'")
+        self.prompt_prefill = prompt_prefill
         cfg, dev = w.cfg, w.device
         self.w, self.cfg, self.dev = w, cfg, dev
         d, da = cfg.model.decoder, cfg.data
@@ -230,9 +236,8 @@ class DecodeSession:
         if not (2 <= self.max_tokens <= self.T):
             raise ValueError(f"max_tokens must be in [2, {self.T}]")
         self.kv_code = {"f32": hb.KV_F32, "float32": hb.KV_F32, "bf16": hb.KV_BF16, "bfloat16": hb.KV_BF16}[kv_dtype]
-        import os as _os
         # bf16 caches keep V blocked as [key/32][128][32] for the MFMA attention kernel
-        self.v_blocked = int(self.kv_code == hb.KV_BF16 and _os.environ.get("DIA_ATTN_VALU") != "1")
+        self.v_blocked = int(self.kv_code == hb.KV_BF16 and attention != "valu")
         kvt = torch.float32 if self.kv_code == hb.KV_F32 else torch.bfloat16
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.lens = [int(len(t)) for t in text_ids]
@@ -545,9 +550,8 @@ class DecodeSession:
     def _prompt_prefill_batched(self) -> bool:
         """The batched MFMA prefill of the prompt rows needs bf16 caches with the blocked V layout and an
         uncompacted decoder; everything else replays the prompt rows through the decode step (first_step)."""
-        import os as _os
         return (any(f > 2 for f in self.first_steps) and self.v_blocked == 1 and not self.w.compacted and not self.teacher
-                and _os.environ.get("DIA_PROMPT_REPLAY") != "1")
+                and self.prompt_prefill != "replay")
 
     def _prompt_prefill(self, st):
         """Decoder.forward in prefill mode (layers.py:722-766) for the audio prompts of all utterances at once, with

@@ -40,6 +40,32 @@ def encode_text(text: str, cfg: DiaConfig) -> np.ndarray:
     return np.frombuffer(raw, dtype=np.uint8).astype(np.int32)
 
 
+SYNTH_SENTENCE = "[S1] Dia is an open weights text to dialogue model. [S2] You get full control over scripts and voices. "
+
+
+def synthetic_text(n_bytes: int, cfg: DiaConfig) -> str:
+    """A dialogue prompt that encodes to exactly `n_bytes` byte tokens after ``effective_text`` (the fixed
+    [S1]/[S2] sentence of SURVEY.md §8d repeated and cut, filled up with '.' where the cut would fall short:
+    tags count one byte each, the closing tag appended by ``generate`` two).  Bench / test input only."""
+    if n_bytes < 8:
+        raise ValueError("synthetic_text: at least 8 bytes")
+    if n_bytes > cfg.data.text_length:
+        raise ValueError("synthetic_text: longer than text_length")
+    reps = SYNTH_SENTENCE * (n_bytes // 40 + 2)
+    best = None
+    for cut in range(len(reps), 3, -1):
+        t = reps[:cut].rstrip()
+        if t.endswith("]") or t.endswith("[") or t[-2:] in ("[S", "S1", "S2"):
+            continue                                 # never end inside or on a tag
+        n = len(effective_text(t).encode("utf-8").replace(b"[S1]", b"\x01").replace(b"[S2]", b"\x02"))    # untruncated
+        if n <= n_bytes:
+            best = t + "." * (n_bytes - n)
+            break
+    if best is None or len(encode_text(effective_text(best), cfg)) != n_bytes:
+        raise ValueError(f"synthetic_text: cannot build {n_bytes} bytes")
+    return best
+
+
 def padded_text_ids(ids: np.ndarray, cfg: DiaConfig) -> np.ndarray:
     out = np.full((cfg.data.text_length,), cfg.data.text_pad_value, dtype=np.int64)
     out[: len(ids)] = ids

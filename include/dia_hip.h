@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DIA_ABI_VERSION 2
+#define DIA_ABI_VERSION 3
 
 #define DIA_OK 0
 #define DIA_E_ARG (-1)     /* bad argument / unsupported shape */
@@ -44,6 +44,16 @@ const char* dia_last_error(void);
 int dia_abi_version(void);
 /* number of visible HIP devices, or a negative error */
 int dia_device_count(void);
+/* Tuning / debug overrides of the launch heuristics (process-wide; csrc/tuning.hpp lists the knobs, e.g. "attn_nz",
+ * "gemm_spw", "wo_sk").  value < 0 clears a knob.  Nothing on the launch path reads the environment; the DIA_TUNE
+ * variable ("name=value,...") is read once when the first engine or kernel is initialised.  The reference has no
+ * counterpart (its only switches are torch.compile / dtype, model.py:631-647). */
+int dia_set_tuning(const char* name, int value);
+int dia_get_tuning(const char* name);
+/* 1 when the library was built with EXPERIMENTS=1 (measured-and-rejected kernels: dia_mlp_fused, the sparse weight
+ * stream of dia_gemm_args.sp_blocks, earlier two-m-tile GEMM forms); 0 for the product build, in which those entry
+ * points fail with DIA_E_ARG */
+int dia_has_experiments(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level entry points (unit parity tests call these; the engine below chains them).
@@ -152,8 +162,9 @@ typedef struct {
   void* vc;
   const int32_t* cur;       /* SELF/CROSS: per-utterance current step (device) */
   const int32_t* len;       /* CROSS: per-utterance text length (device); ENC: unused */
-  int32_t enc_len;          /* ENC: L */
-  int32_t _pad0;
+  int32_t enc_len;          /* ENC: L (== n_rows, <= kv_cap) */
+  int32_t rope_rows;        /* rows of cos_t / sin_t, or 0 = not stated.  When stated, dia_attn refuses shapes whose RoPE
+                             * position could leave the tables (SELF: kv_cap + 1 rows needed, ENC: enc_len) */
   const float* cos_t;
   const float* sin_t;
   void* P;                  /* output planes [3][mtiles][p_ktiles][64][8] */

@@ -35,7 +35,7 @@ for B, cur, T in ((1, 1040, 3072), (8, 1040, 3072), (8, 300, 3072), (8, 2500, 30
     scr = torch.zeros(L.dia_attn_scratch_floats(R, KVH, T), device=d); tk = torch.zeros(R * KVH, dtype=torch.int32, device=d)
     a.scratch, a.tickets, a.v_blocked = hb.ptr(scr), hb.ptr(tk), 1
     nz = min((512 + R * KVH - 1) // (R * KVH), T // 128)
-    if os.environ.get("DIA_DBG_NZ"): nz = int(os.environ["DIA_DBG_NZ"])
+    if hb.lib().dia_get_tuning(b"attn_nz") > 0: nz = hb.lib().dia_get_tuning(b"attn_nz")      # DIA_TUNE=attn_nz=N
     big = torch.empty(1 << 28, dtype=torch.uint8, device=d)
     for _ in range(3):
         hb.check(L.dia_attn(C.byref(a), None), "attn")

@@ -13,8 +13,8 @@ for B, tp in ((1, 430), (8, 430)):
     ids = [encode_text(effective_text(text, "[S1] prompt transcript."), cfg)] * B
     prompts = [np.random.RandomState(b).randint(0, 1024, size=(tp, 9)).astype(np.int32) for b in range(B)]
     for replay in (0, 1):
-        os.environ["DIA_PROMPT_REPLAY"] = str(replay)
-        s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=tp + 66, seeds=list(range(B)), audio_prompts=prompts, ignore_eos=True)
+        s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=tp + 66, seeds=list(range(B)), audio_prompts=prompts, ignore_eos=True,
+                          prompt_prefill="replay" if replay else "auto")
         s.prefill(); s.sync()                      # warm (allocator, modules)
         s.cur.fill_(1); t0 = time.time(); s.prefill(); s.sync(); t1 = time.time()
         n = (tp + 1) - int(s.cur.min().item())     # replay steps still to do before the first sampled step

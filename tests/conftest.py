@@ -22,3 +22,18 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return load
+
+
+@pytest.fixture
+def tuning():
+    """set launch-heuristic overrides (dia_set_tuning) for one test; every knob touched is cleared afterwards"""
+    from dia_hip import binding as hb
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        hb.set_tuning(name, value)
+
+    yield set_
+    for name in touched:
+        hb.set_tuning(name, -1)

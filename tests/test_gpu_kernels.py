@@ -129,257 +129,11 @@ def test_gemm_split_k_resid(M, K, D, sk):
     assert torch.equal(lay.unpack_planes(outs[0][1], M, D), outs[0][0] * gn)
 
 
-@pytest.mark.parametrize("M,K,N,epi", [(2, 2048, 4096, "swiglu"), (4, 2048, 2048, "resid"), (1, 1024, 1024, "store"), (2, 512, 4096, "swiglu")])
-def test_gemv_sparse_stream(M, K, N, epi):
-    """unstructured-pruned matrix as a zero-skipping stream (layout.sparse_tile_weight): bit-identical to the dense
-    tiles of the same matrix, through every epilogue; a dense corner exercises the raw-tile escape."""
-    d = dev()
-    torch.manual_seed(K + N + M)
-    W = bf16r(torch.randn(K, N, device=d) * 0.05)
-    W[torch.rand_like(W) < 0.5] = 0
-    W[: 64, : 32] = bf16r(torch.randn(64, 32, device=d) * 0.05 + 0.5)          # fully dense tiles -> stored raw
-    W[: 64, N // 2: N // 2 + 32] = bf16r(torch.randn(64, 32, device=d) * 0.05 + 0.5)   # (the "up" half too, for the interleaved wi layout)
-    x = torch.randn(M, K, device=d)
-    mpad = 16
-    ssq = strip_ssq(x, mpad)
-    A = lay.pack_planes(x)
-    if epi == "swiglu":
-        Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(W.reshape(K, 2, N // 2)))
-    else:
-        Wt, kt, ns = lay.tile_weight(W)
-    blocks, toff = lay.sparse_tile_weight(Wt)
-    assert int(((toff & 255) == 0).sum()) >= 1 and blocks.numel() < 0.7 * Wt.numel() * 2
-    gn = bf16r(1.0 + 0.1 * torch.randn(N, device=d))
-    outs = []
-    for sparse in (False, True):
-        g = hb.GemmArgs()
-        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
-        g.KT, g.nstrips = kt, ns
-        if sparse:
-            g.sp_blocks, g.sp_toff = hb.ptr(blocks), hb.ptr(toff)
-        else:
-            g.W, g.nw = hb.ptr(Wt), 16                 # the same 16-wave K split as the sparse kernel: identical summation order
-        g.ssq_ld = mpad
-        out = torch.zeros(mpad, N, device=d)
-        P = torch.zeros(3, 1, max(N // 32, 1), 64, 8, dtype=torch.bfloat16, device=d)
-        sso = torch.zeros(ns, mpad, device=d)
-        if epi == "swiglu":
-            g.epi = hb.EPI_SWIGLU_EMIT
-            g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq), K // 16, 1.0 / K, 1e-5
-            g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), P.shape[2]
-        elif epi == "resid":
-            g.epi = hb.EPI_RESID_EMIT
-            out[:M] = torch.randn(M, N, device=d, generator=torch.Generator(device=d).manual_seed(1))
-            g.out, g.ldo, g.gnext = hb.ptr(out), N, hb.ptr(gn)
-            g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), P.shape[2], hb.ptr(sso)
-        else:
-            g.epi = hb.EPI_SCALE_STORE
-            g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq), K // 16, 1.0 / K, 1e-5
-            g.out, g.ldo = hb.ptr(out), N
-        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
-        torch.cuda.synchronize()
-        outs.append((out.clone(), P.clone(), sso.clone()))
-    for a_, b_ in zip(outs[0], outs[1]):
-        assert torch.equal(a_, b_)
-    if epi == "store":
-        xd = x.double()
-        ref = (xd @ W.double()) * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
-        assert (outs[1][0][:M].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-
-
-@pytest.mark.parametrize("M", [17, 20, 32])
-def test_gemm_two_mtiles(M, monkeypatch):
-    """17..32 rows (batch 9-16): k_gemm32 — both m-tiles' A fragments in registers; K = 2048 in one workgroup
-    (selected by a debug knob only: it loses to the generic kernel), K = 8192 split four ways by dia_gemm itself
-    when the scratch capacity is stated."""
-    monkeypatch.setenv("DIA_DBG_G32_ALL", "1")
-    monkeypatch.setenv("DIA_DBG_PAIR16", "0")        # not the paired one-m-tile kernel (test_gemm_paired_mtiles)
-    d = dev()
-    torch.manual_seed(M)
-    # SCALE_STORE with the row norm, K = 2048
-    K, N = 2048, 512
-    x = torch.randn(M, K, device=d) * 2.0
-    gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
-    W = bf16r(torch.randn(K, N, device=d) * 0.05)
-    Wt, kt, ns = lay.tile_weight(W)
-    out = torch.full((M, N), float("nan"), device=d)
-    run_gemm(x * gw, Wt, kt, ns, hb.EPI_SCALE_STORE, ssq_in=strip_ssq(x, 32), inv_d=1.0 / K, eps=1e-5, out=out, ldo=N, ssq_ld=32)
-    xd = x.double()
-    ref = ((xd * gw.double()) @ W.double()) * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
-    assert (out.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-    # SWIGLU, K = 2048
-    F = 1024
-    wi = bf16r(torch.randn(K, 2, F, device=d) * 0.05)
-    Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi))
-    P = torch.zeros(3, 2, F // 32, 64, 8, dtype=torch.bfloat16, device=d)
-    run_gemm(x * gw, Wt, kt, ns, hb.EPI_SWIGLU_EMIT, ssq_in=strip_ssq(x, 32), inv_d=1.0 / K, eps=1e-5, P=P, p_kt=F // 32, ssq_ld=32)
-    h = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
-    f = torch.einsum("mk,kgf->mgf", h, wi.double())
-    ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
-    assert (lay.unpack_planes(P, M, F).double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-    # persistent two-half form (k_gemm32m): K = 2048, >= 128 strips, scratch lent -> SWIGLU again + RESID_EMIT
-    monkeypatch.delenv("DIA_DBG_G32_ALL")
-    monkeypatch.setenv("DIA_DBG_G32M", "1")
-    F2 = 2048
-    wi2 = bf16r(torch.randn(K, 2, F2, device=d) * 0.05)
-    Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi2))
-    A = lay.pack_planes(x * gw)
-    scr = torch.zeros(ns * 2 * 512, device=d); tk = torch.zeros(ns, dtype=torch.int32, device=d)
-    ss = strip_ssq(x, 32)
-    for _ in range(2):
-        P = torch.zeros(3, 2, F2 // 32, 64, 8, dtype=torch.bfloat16, device=d)
-        g = hb.GemmArgs()
-        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
-        g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_SWIGLU_EMIT
-        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, 32
-        g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), F2 // 32
-        g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = hb.ptr(scr), hb.ptr(tk), scr.numel()
-        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
-    torch.cuda.synchronize()
-    assert (tk == 0).all()
-    f = torch.einsum("mk,kgf->mgf", h, wi2.double())
-    ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
-    assert (lay.unpack_planes(P, M, F2).double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-    Dn = 2048
-    Wn = bf16r(torch.randn(K, Dn, device=d) * 0.03)
-    xn0 = torch.randn(M, Dn, device=d); gnn = bf16r(1.0 + 0.1 * torch.randn(Dn, device=d))
-    Wt, kt, ns = lay.tile_weight(Wn)
-    An = lay.pack_planes(x)
-    xr = xn0.clone()
-    Pn = torch.zeros(3, 2, Dn // 32, 64, 8, dtype=torch.bfloat16, device=d); ssqn = torch.zeros(ns, 32, device=d)
-    scr = torch.zeros(ns * 2 * 512, device=d); tk = torch.zeros(ns, dtype=torch.int32, device=d)
-    g = hb.GemmArgs()
-    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(An), An[0].numel(), An.shape[2], M
-    g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_RESID_EMIT
-    g.ssq_ld, g.out, g.ldo, g.gnext = 32, hb.ptr(xr), Dn, hb.ptr(gnn)
-    g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(Pn), Pn[0].numel(), Dn // 32, hb.ptr(ssqn)
-    g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = hb.ptr(scr), hb.ptr(tk), scr.numel()
-    hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
-    torch.cuda.synchronize()
-    refn = xn0.double() + x.double() @ Wn.double()
-    assert (xr.double() - refn).abs().max().item() <= 2e-5 * refn.abs().max().item()
-    assert torch.equal(lay.unpack_planes(Pn, M, Dn), xr * gnn)
-    want = (xr.double() ** 2).reshape(M, Dn // 16, 16).sum(-1).T
-    assert (ssqn[:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
-    # RESID_EMIT, K = 8192: split-K 4 inside dia_gemm, twice for reproducibility
-    K2, D = 8192, 256
-    a = torch.randn(M, K2, device=d)
-    W2 = bf16r(torch.randn(K2, D, device=d) * 0.03)
-    x0 = torch.randn(M, D, device=d)
-    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
-    Wt, kt, ns = lay.tile_weight(W2)
-    A = lay.pack_planes(a)
-    scr = torch.zeros(ns * 4 * 512, device=d); tk = torch.zeros(ns, dtype=torch.int32, device=d)
-    outs = []
-    for _ in range(2):
-        xr = x0.clone()
-        P = torch.zeros(3, 2, D // 32, 64, 8, dtype=torch.bfloat16, device=d)
-        ssq = torch.zeros(ns, 32, device=d)
-        g = hb.GemmArgs()
-        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
-        g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_RESID_EMIT
-        g.ssq_ld, g.out, g.ldo, g.gnext = 32, hb.ptr(xr), D, hb.ptr(gn)
-        g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), D // 32, hb.ptr(ssq)
-        g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = hb.ptr(scr), hb.ptr(tk), scr.numel()
-        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
-        torch.cuda.synchronize()
-        outs.append((xr, P, ssq))
-    assert (tk == 0).all()
-    ref = x0.double() + a.double() @ W2.double()
-    assert (outs[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert torch.equal(lay.unpack_planes(outs[0][1], M, D), outs[0][0] * gn)
-    want = (outs[0][0].double() ** 2).reshape(M, D // 16, 16).sum(-1).T
-    assert (outs[0][2][:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
-
-
-@pytest.mark.parametrize("M", [5, 8, 13, 16])
-def test_gemm_row_groups(M, monkeypatch):
-    """5..16 rows (batch 3-8), K <= 2048, strips x groups <= 512: the 4-row kernel over row groups of 4 (gridDim.z;
-    kernel-level experiment behind DIA_DBG_ZSMALL).
-    Every epilogue against float64, and bit for bit against the same kernel run on each 4-row slice alone."""
-    monkeypatch.setenv("DIA_DBG_ZSMALL", "512")      # opt-in: measured slower than k_gemm16 in the decode step
-    d = dev()
-    torch.manual_seed(300 + M)
-    L = hb.lib()
-
-    def args(A, M_, Wt, kt, ns, epi):
-        g = hb.GemmArgs()
-        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M_
-        g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, epi
-        return g
-
-    groups = [slice(r, min(r + 4, M)) for r in range(0, M, 4)]
-    for K, N in ((2048, 2048), (1024, 592), (512, 1024)):
-        x = torch.randn(M, K, device=d) * 2.0
-        gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
-        xd = x.double()
-        inv = torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
-        W = bf16r(torch.randn(K, N, device=d) * 0.05)
-        Wt, kt, ns = lay.tile_weight(W)
-        # SCALE_STORE
-        outs = []
-        for rows in [slice(0, M)] + groups:
-            xs = x[rows]
-            A = lay.pack_planes(xs * gw)
-            out = torch.full((xs.shape[0], N), float("nan"), device=d)
-            sr = strip_ssq(xs, 16)
-            g = args(A, xs.shape[0], Wt, kt, ns, hb.EPI_SCALE_STORE)
-            g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(sr), K // 16, 1.0 / K, 1e-5, 16
-            g.out, g.ldo = hb.ptr(out), N
-            hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
-            torch.cuda.synchronize()
-            outs.append(out)
-        ref = ((xd * gw.double()) @ W.double()) * inv
-        assert (outs[0].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-        if ns * len(groups) <= 512:             # the row-group form ran: identical to its 4-row pieces
-            assert torch.equal(outs[0], torch.cat(outs[1:]))
-        # RESID_EMIT into D = N
-        x0 = torch.randn(M, N, device=d)
-        gn = bf16r(1.0 + 0.1 * torch.randn(N, device=d))
-        A2 = lay.pack_planes(x)
-        pkt = (N + 31) // 32
-        xr = x0.clone()
-        P = torch.zeros(3, 1, pkt, 64, 8, dtype=torch.bfloat16, device=d)
-        ssq = torch.zeros(ns, 16, device=d)
-        g = args(A2, M, Wt, kt, ns, hb.EPI_RESID_EMIT)
-        g.ssq_ld, g.out, g.ldo, g.gnext = 16, hb.ptr(xr), N, hb.ptr(gn)
-        g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), pkt, hb.ptr(ssq)
-        hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
-        torch.cuda.synchronize()
-        ref = x0.double() + xd @ W.double()
-        assert (xr.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
-        assert torch.equal(lay.unpack_planes(P, M, pkt * 32)[:, :N], xr * gn)
-        want = (xr.double() ** 2).reshape(M, N // 16, 16).sum(-1).T
-        assert (ssq[:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
-        assert (ssq[:, M:] == 0).all()
-    # SWIGLU_EMIT: K = 1024, F = 512 (64 strips)
-    K, F = 1024, 512
-    x = torch.randn(M, K, device=d) * 2.0
-    gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
-    xd = x.double()
-    wi = bf16r(torch.randn(K, 2, F, device=d) * 0.05)
-    Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi))
-    A = lay.pack_planes(x * gw)
-    ss = strip_ssq(x, 16)
-    P = torch.zeros(3, 1, F // 32, 64, 8, dtype=torch.bfloat16, device=d)
-    g = args(A, M, Wt, kt, ns, hb.EPI_SWIGLU_EMIT)
-    g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, 16
-    g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), F // 32
-    hb.check(L.dia_gemm(C.byref(g), None), "dia_gemm")
-    torch.cuda.synchronize()
-    h = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
-    f = torch.einsum("mk,kgf->mgf", h, wi.double())
-    ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
-    assert (lay.unpack_planes(P, M, F).double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-
-
 @pytest.mark.parametrize("M", [17, 23, 32, 40, 64, 100, 128])
-def test_gemm_paired_mtiles(M, monkeypatch):
+def test_gemm_paired_mtiles(M):
     """17..64 rows (batch 9-32), default path: the one-m-tile kernel launched over all m-tiles (gridDim.z = 2..4).
     Every epilogue, persistent and one-strip forms, split-K 4; rows 0..15 must equal the 16-row launch bit for bit
     (same kernel, same summation order), rows 16.. the 16-row launch on those rows."""
-    monkeypatch.delenv("DIA_DBG_PAIR16", raising=False)
     d = dev()
     torch.manual_seed(200 + M)
     L = hb.lib()
@@ -474,100 +228,6 @@ def test_gemm_paired_mtiles(M, monkeypatch):
     assert L.dia_gemm(C.byref(g), None) != 0
 
 
-@pytest.mark.parametrize("form", ["16,2", "16,1", "8,2", "8,1"])
-@pytest.mark.parametrize("M", [17, 23, 32])
-def test_gemm_blk32(M, form, monkeypatch):
-    """17..32 rows (batch 9-16): k_gemm_blk32 — column blocks x K ranges, one slab hand-off per block.  All four
-    forms (k-tiles per range, strips per wave), the three decode epilogues, strip counts that are not whole
-    blocks, twice for bit-reproducibility, tickets re-armed."""
-    monkeypatch.setenv("DIA_DBG_BLK32", form)
-    monkeypatch.setenv("DIA_DBG_PAIR16", "0")
-    kr, ws = (int(v) for v in form.split(","))
-    d = dev()
-    torch.manual_seed(100 + M)
-
-    def lend(g, ns, kt):
-        blocks = (ns + 8 * ws - 1) // (8 * ws)
-        scr = torch.zeros(blocks * (kt // kr) * 512 * 8 * ws, device=d)
-        tk = torch.zeros(ns, dtype=torch.int32, device=d)
-        g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = hb.ptr(scr), hb.ptr(tk), scr.numel()
-        return scr, tk
-
-    # SCALE_STORE with the row norm: K = 2048, 37 strips (a partial last block)
-    K, N = 2048, 37 * 16
-    x = torch.randn(M, K, device=d) * 2.0
-    gw = bf16r(1.0 + 0.1 * torch.randn(K, device=d))
-    W = bf16r(torch.randn(K, N, device=d) * 0.05)
-    Wt, kt, ns = lay.tile_weight(W)
-    A = lay.pack_planes(x * gw)
-    ss = strip_ssq(x, 32)
-    outs = []
-    for _ in range(2):
-        out = torch.full((M, N), float("nan"), device=d)
-        g = hb.GemmArgs()
-        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
-        g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_SCALE_STORE
-        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, 32
-        g.out, g.ldo = hb.ptr(out), N
-        scr, tk = lend(g, ns, kt)
-        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
-        torch.cuda.synchronize()
-        assert (tk == 0).all() and scr.abs().sum().item() > 0        # the split kernel ran and re-armed its tickets
-        outs.append(out)
-    xd = x.double()
-    ref = ((xd * gw.double()) @ W.double()) * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
-    assert (outs[0].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-    assert torch.equal(outs[0], outs[1])
-    # SWIGLU_EMIT: K = 2048, F = 2048 (256 strips)
-    F = 2048
-    wi = bf16r(torch.randn(K, 2, F, device=d) * 0.05)
-    Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wi))
-    P = torch.zeros(3, 2, F // 32, 64, 8, dtype=torch.bfloat16, device=d)
-    g = hb.GemmArgs()
-    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
-    g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_SWIGLU_EMIT
-    g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ss), K // 16, 1.0 / K, 1e-5, 32
-    g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), F // 32
-    scr, tk = lend(g, ns, kt)
-    hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
-    torch.cuda.synchronize()
-    assert (tk == 0).all()
-    h = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
-    f = torch.einsum("mk,kgf->mgf", h, wi.double())
-    ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
-    assert (lay.unpack_planes(P, M, F).double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-    # RESID_EMIT: K = 8192 (16 or 32 ranges), D = 2048; and K = 512 into D = 272 (17 strips)
-    for K2, D in ((8192, 2048), (512, 272)):
-        a = torch.randn(M, K2, device=d)
-        W2 = bf16r(torch.randn(K2, D, device=d) * 0.03)
-        x0 = torch.randn(M, D, device=d)
-        gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
-        Wt, kt, ns = lay.tile_weight(W2)
-        A2 = lay.pack_planes(a)
-        pkt = (D + 31) // 32
-        res = []
-        for _ in range(2):
-            xr = x0.clone()
-            P = torch.zeros(3, 2, pkt, 64, 8, dtype=torch.bfloat16, device=d)
-            ssq = torch.zeros(ns, 32, device=d)
-            g = hb.GemmArgs()
-            g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A2), A2[0].numel(), A2.shape[2], M
-            g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, hb.EPI_RESID_EMIT
-            g.ssq_ld, g.out, g.ldo, g.gnext = 32, hb.ptr(xr), D, hb.ptr(gn)
-            g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), pkt, hb.ptr(ssq)
-            scr, tk = lend(g, ns, kt)
-            hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
-            torch.cuda.synchronize()
-            assert (tk == 0).all()
-            res.append((xr, P, ssq))
-        ref = x0.double() + a.double() @ W2.double()
-        assert (res[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
-        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
-        assert torch.equal(lay.unpack_planes(res[0][1], M, pkt * 32)[:, :D], res[0][0] * gn)
-        want = (res[0][0].double() ** 2).reshape(M, D // 16, 16).sum(-1).T
-        assert (res[0][2][:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
-
-
 @pytest.mark.parametrize("M,K,F", [(2, 2048, 8192), (16, 256, 512), (33, 512, 1024)])
 def test_gemm_swiglu_emit(M, K, F):
     d = dev()
@@ -586,78 +246,6 @@ def test_gemm_swiglu_emit(M, K, F):
     ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
     got = lay.unpack_planes(P, M, F).double()
     assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
-
-
-@pytest.mark.parametrize("M,D,F", [(2, 512, 1024), (1, 512, 1024), (2, 2048, 8192)])
-def test_mlp_fused(M, D, F):
-    """dia_mlp_fused: wi (SwiGLU) and wo (residual + planes + ssq) in one persistent launch with a grid barrier,
-    against float64 and against the two separate launches; repeated launches reuse the barrier counter."""
-    d = dev()
-    torch.manual_seed(D + M)
-    x = torch.randn(M, D, device=d)
-    gw = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
-    wi = bf16r(torch.randn(D, 2, F, device=d) * 0.05)
-    wo = bf16r(torch.randn(F, D, device=d) * 0.03)
-    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
-    x0 = torch.randn(M, D, device=d)
-    Wi, kti, nsi = lay.tile_weight(lay.interleave_gate_up(wi))
-    Wo, kto, nso = lay.tile_weight(wo)
-    A = lay.pack_planes(x * gw)
-    ssq_in = strip_ssq(x, 16)
-    L = hb.lib()
-
-    def args(xres, Ph, Px, ssq_out, skscr, sktk):
-        a = hb.GemmArgs()
-        a.A, a.a_plane_stride, a.a_ktiles, a.M = hb.ptr(A), A[0].numel(), A.shape[2], M
-        a.W, a.KT, a.nstrips, a.epi = hb.ptr(Wi), kti, nsi, hb.EPI_SWIGLU_EMIT
-        a.ssq_in, a.ssq_in_n, a.inv_d, a.eps, a.ssq_ld = hb.ptr(ssq_in), D // 16, 1.0 / D, 1e-5, 16
-        a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(Ph), Ph[0].numel(), F // 32
-        b = hb.GemmArgs()
-        b.A, b.a_plane_stride, b.a_ktiles, b.M = hb.ptr(Ph), Ph[0].numel(), F // 32, M
-        b.W, b.KT, b.nstrips, b.epi = hb.ptr(Wo), kto, nso, hb.EPI_RESID_EMIT
-        b.ssq_ld, b.out, b.ldo, b.gnext = 16, hb.ptr(xres), D, hb.ptr(gn)
-        b.P, b.p_plane_stride, b.p_ktiles, b.ssq_out = hb.ptr(Px), Px[0].numel(), D // 32, hb.ptr(ssq_out)
-        b.sk_scratch, b.sk_tickets, b.sk = hb.ptr(skscr), hb.ptr(sktk), 2
-        return a, b
-
-    def fresh():
-        return (x0.clone(), torch.zeros(3, 1, F // 32, 64, 8, dtype=torch.bfloat16, device=d),
-                torch.zeros(3, 1, D // 32, 64, 8, dtype=torch.bfloat16, device=d), torch.zeros(D // 16, 16, device=d),
-                torch.zeros((D // 16) * 4 * 256, device=d), torch.zeros(D // 16, dtype=torch.int32, device=d))
-
-    bar = torch.zeros(2, dtype=torch.int32, device=d)
-    outs = []
-    for rep in range(3):                                   # the counter keeps counting across launches
-        bufs = fresh()
-        a, b = args(*bufs)
-        hb.check(L.dia_mlp_fused(C.byref(a), C.byref(b), hb.ptr(bar), None), "dia_mlp_fused")
-        torch.cuda.synchronize()
-        outs.append(bufs)
-    assert bar.tolist() == [3 * 2 * nso, 0] and (outs[0][5] == 0).all()
-    xd = x.double()
-    hdn = (xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)) * gw.double()
-    f = torch.einsum("mk,kgf->mgf", hdn, wi.double())
-    h_ref = torch.nn.functional.silu(f[:, 0]) * f[:, 1]
-    xr, Ph, Px, ssq_o = outs[0][:4]
-    h_got = lay.unpack_planes(Ph, M, F)
-    assert (h_got.double() - h_ref).abs().max().item() <= 2e-5 * max(1.0, h_ref.abs().max().item())
-    ref = x0.double() + h_got.double() @ wo.double()       # wo consumes the fp32 h the planes carry
-    assert (xr.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
-    assert torch.equal(lay.unpack_planes(Px, M, D), xr * gn)
-    want = (xr.double() ** 2).reshape(M, D // 16, 16).sum(-1).T
-    assert (ssq_o[:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
-    for o in outs[1:]:
-        assert torch.equal(o[0], xr) and torch.equal(o[2], Px)            # bit-reproducible
-    # the two separate launches agree to fp32 rounding (their waves split K differently)
-    bufs = fresh()
-    a, b = args(*bufs)
-    hb.check(L.dia_gemm(C.byref(a), None), "wi"); hb.check(L.dia_gemm(C.byref(b), None), "wo")
-    torch.cuda.synchronize()
-    assert (lay.unpack_planes(bufs[1], M, F) - h_got).abs().max().item() <= 1e-5 * max(1.0, h_ref.abs().max().item())
-    assert (bufs[0] - xr).abs().max().item() <= 1e-5 * ref.abs().max().item()
-    # shapes that do not chain are refused, nothing is launched
-    b.KT = kto // 2
-    assert L.dia_mlp_fused(C.byref(a), C.byref(b), hb.ptr(bar), None) == -1
 
 
 @pytest.mark.parametrize("kvd", ["f32", "bf16"])
@@ -708,11 +296,11 @@ def attn_ref(q, K, V):
 @pytest.mark.parametrize("kvd", ["f32", "bf16"])
 @pytest.mark.parametrize("B,cur,nz", [(1, 1, 0), (1, 37, 0), (1, 128, 0), (1, 129, 0), (2, 300, 0), (1, 1025, 0), (1, 1280, 0),
                                       (1, 1025, 1), (2, 300, 2), (1, 1280, 3), (1, 640, 2)])
-def test_attn_self(kvd, B, cur, nz, monkeypatch):
+def test_attn_self(kvd, B, cur, nz, tuning):
     """nz > 0 forces the key-split factor: few workgroups -> several rounds per wave (prefetch path, the
     new slot in a later round), many -> one granule per wave."""
     if nz:
-        monkeypatch.setenv("DIA_DBG_NZ", str(nz))
+        tuning("attn_nz", nz)
     d = dev()
     torch.manual_seed(cur)
     R, QH, KVH, T = 2 * B, 16, 4, 1280
@@ -999,3 +587,180 @@ def test_error_paths_on_device():
     Wt = torch.zeros(1, 4, 64, 8, dtype=torch.bfloat16, device=d)
     g.A, g.a_plane_stride, g.a_ktiles, g.M, g.W, g.KT, g.nstrips = hb.ptr(A), A[0].numel(), 2, 2, hb.ptr(Wt), 4, 1
     assert L.dia_gemm(C.byref(g), None) == -1 and b"exceeds" in L.dia_last_error()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Compaction maps of structured-pruned checkpoints (dia_gemm_args.cmap / strip_map, dia_attn_args.head_map):
+# every row-count class the decode step dispatches to — k_gemv_small (M <= 4), k_gemm16 (5..16 rows, one strip
+# per workgroup and the persistent multi-strip form), the z-form over 2..3 m-tiles — against float64.
+# ---------------------------------------------------------------------------------------------------
+def _gemm_args(X, Wt, kt, ns, epi, akt=None):
+    A = lay.pack_planes(X, ktiles=akt)
+    g = hb.GemmArgs()
+    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], X.shape[0]
+    g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wt), kt, ns, epi
+    return g, A
+
+
+@pytest.mark.parametrize("M,K,D,sk", [(2, 2048, 2048, 0), (4, 1024, 512, 0), (6, 2048, 2048, 0), (16, 2048, 2048, 0), (16, 1024, 2048, 0),
+                                      (16, 4096, 2048, 4), (20, 2048, 2048, 0), (32, 2048, 2048, 0), (32, 4096, 2048, 4), (40, 512, 512, 0),
+                                      (2, 4096, 2048, 2)])
+def test_gemm_resid_emit_cmap(M, K, D, sk):
+    """RESID_EMIT into a compacted consumer: residual column n is emitted at plane position cmap[n] (or dropped),
+    x and the strip sums of squares stay at full width."""
+    d = dev()
+    torch.manual_seed(M + K + D)
+    a = torch.randn(M, K, device=d)
+    W = bf16r(torch.randn(K, D, device=d) * 0.03)
+    x0 = torch.randn(M, D, device=d)
+    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+    keep = torch.rand(D, device=d) < 0.5
+    keep[:3] = torch.tensor([True, False, True], device=d)
+    nk = int(keep.sum())
+    ckt = D // 32                                   # the engine's planes keep the full width; the consumer reads KT < ckt
+    cmap = torch.where(keep, torch.cumsum(keep.int(), 0) - 1, torch.full((D,), -1, device=d, dtype=torch.int64)).to(torch.int32)
+    Wt, kt, ns = lay.tile_weight(W)
+    mpad = (M + 15) // 16 * 16
+    x = x0.clone()
+    sentinel = 3.0
+    P = lay.pack_planes(torch.full((mpad, ckt * 32), sentinel, device=d))
+    ssq = torch.zeros(ns, mpad, device=d)
+    g, A = _gemm_args(a, Wt, kt, ns, hb.EPI_RESID_EMIT)
+    g.ssq_ld, g.out, g.ldo, g.gnext = mpad, hb.ptr(x), D, hb.ptr(gn)
+    g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out, g.cmap = hb.ptr(P), P[0].numel(), ckt, hb.ptr(ssq), hb.ptr(cmap)
+    if sk:
+        scr = torch.zeros(mpad // 16 * ns * sk * 256, device=d)
+        tk = torch.zeros(mpad // 16 * ns, dtype=torch.int32, device=d)
+        g.sk_scratch, g.sk_tickets, g.sk, g.sk_scratch_floats = hb.ptr(scr), hb.ptr(tk), sk, scr.numel()
+    hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+    torch.cuda.synchronize()
+    ref = x0.double() + a.double() @ W.double()
+    assert (x.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    got = lay.unpack_planes(P, mpad, ckt * 32)
+    assert torch.equal(got[:M, :nk], (x * gn)[:, keep])               # compacted order, fp32-exact
+    assert (got[:M, nk:] == sentinel).all() and (got[M:] == sentinel).all()   # nothing else is written
+    want = (x.double() ** 2).reshape(M, D // 16, 16).sum(-1).T
+    assert (ssq[:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
+
+
+@pytest.mark.parametrize("M,K,heads,live", [(2, 2048, 16, 9), (4, 512, 8, 3), (6, 2048, 16, 9), (16, 2048, 24, 13), (16, 1792, 16, 7),
+                                            (20, 2048, 16, 9), (32, 1792, 24, 13), (48, 512, 8, 5)])
+def test_gemm_scale_store_strip_map(M, K, heads, live):
+    """SCALE_STORE of a matrix whose dead heads were dropped: compact strip s lands at the 16 columns of original
+    strip strip_map[s]; columns of dropped heads are not written."""
+    d = dev()
+    torch.manual_seed(M * 3 + K + heads)
+    N = heads * 128
+    x = torch.randn(M, K, device=d)
+    W = bf16r(torch.randn(K, N, device=d) * 0.05)
+    lh = torch.zeros(heads, dtype=torch.bool)
+    lh[torch.randperm(heads)[:live]] = True
+    strips = []
+    for h in torch.nonzero(lh).flatten().tolist():
+        strips += list(range(h * 8, h * 8 + 8))
+    cols = (torch.tensor(strips)[:, None] * 16 + torch.arange(16)[None, :]).reshape(-1).to(d)
+    Wt, kt, ns = lay.tile_weight(W[:, cols])
+    assert ns == live * 8
+    smap = torch.tensor(strips, dtype=torch.int32, device=d)
+    mpad = (M + 15) // 16 * 16
+    ssq = strip_ssq(x, mpad)
+    out = torch.full((M, N), float("nan"), device=d)
+    g, A = _gemm_args(x, Wt, kt, ns, hb.EPI_SCALE_STORE)
+    g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ssq), ssq.shape[0], 1.0 / K, 1e-5, mpad
+    g.out, g.ldo, g.strip_map = hb.ptr(out), N, hb.ptr(smap)
+    hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+    torch.cuda.synchronize()
+    xd = x.double()
+    ref = (xd @ W.double()) * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+    livec = torch.zeros(N, dtype=torch.bool, device=d)
+    livec[cols] = True
+    err = (out[:, livec].double() - ref[:, livec]).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    assert torch.isnan(out[:, ~livec]).all()
+
+
+@pytest.mark.parametrize("M,K,F,live", [(2, 2048, 8192, 4096), (16, 1024, 8192, 3072), (16, 2048, 2048, 1024), (32, 1024, 4096, 2048)])
+def test_gemm_swiglu_emit_compacted_hidden(M, K, F, live):
+    """wi_fused with dead hidden units dropped (gate/up columns taken by index, -1 -> zero column) and a K-compacted
+    input: the hidden planes come out in the compacted order wo's compacted rows expect."""
+    d = dev()
+    torch.manual_seed(M + K + F)
+    x = torch.randn(M, K, device=d)
+    wi3 = bf16r(torch.randn(K, 2, F, device=d) * 0.03)
+    idx = torch.sort(torch.randperm(F, device=d)[:live])[0]
+    pad = (-live) % 256
+    idxp = torch.cat([idx, torch.full((pad,), -1, device=d, dtype=idx.dtype)])
+    take = lambda w2: torch.where((idxp >= 0)[None, :], w2[:, idxp.clamp(min=0)], torch.zeros((), device=d))
+    wc = torch.stack([take(wi3[:, 0]), take(wi3[:, 1])], dim=1)
+    Wt, kt, ns = lay.tile_weight(lay.interleave_gate_up(wc))
+    Fc = idxp.numel()
+    mpad = (M + 15) // 16 * 16
+    ssq = strip_ssq(x, mpad)
+    P = torch.zeros(3, mpad // 16, Fc // 32, 64, 8, dtype=torch.bfloat16, device=d)
+    g, A = _gemm_args(x, Wt, kt, ns, hb.EPI_SWIGLU_EMIT)
+    g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ssq), ssq.shape[0], 1.0 / K, 1e-5, mpad
+    g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), Fc // 32
+    hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+    torch.cuda.synchronize()
+    xd = x.double() * torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-5)
+    gate, up = xd @ wi3[:, 0].double(), xd @ wi3[:, 1].double()
+    ref = (torch.nn.functional.silu(gate) * up)[:, idx]
+    got = lay.unpack_planes(P, M, Fc).double()
+    assert (got[:, :live] - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert (got[:, live:] == 0).all()                                  # padded hidden units: silu(0) * 0
+
+
+@pytest.mark.parametrize("kvd", ["f32", "bf16"])
+@pytest.mark.parametrize("B,cur", [(1, 40), (4, 300), (8, 77)])
+def test_attn_self_head_map(kvd, B, cur):
+    """self-attention of a head-pruned layer: live query head h is emitted at head position head_map[h] of the
+    compacted o_proj input, dead heads emit nothing; stale plane columns beyond the live heads stay untouched."""
+    d = dev()
+    torch.manual_seed(cur + B)
+    R, QH, KVH, T = 2 * B, 16, 4, 512
+    live = torch.tensor([1, 0, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 1, 0, 0], dtype=torch.bool)      # kv head 1 fully dead
+    hmap = torch.where(live, torch.cumsum(live.int(), 0) - 1, torch.full((QH,), -1)).to(torch.int32).to(d)
+    nl = int(live.sum())
+    nq = (QH + 2 * KVH) * 128
+    qkv = torch.randn(R, nq, device=d)
+    kdt = torch.float32 if kvd == "f32" else torch.bfloat16
+    kc = torch.randn(R, KVH, T, 128, device=d).to(kdt)
+    vc = torch.randn(R, KVH, T, 128, device=d).to(kdt)
+    blocked = kvd == "bf16"
+    if blocked:
+        vc = lay.v_to_blocked(vc)
+    cos, sin = [t.to(d) for t in lay.rope_tables(T + 1, 128, 1, 10000)]
+    curs = torch.full((B,), cur, dtype=torch.int32, device=d)
+    mt = (R + 15) // 16
+    sentinel = 5.0
+    P = lay.pack_planes(torch.full((mt * 16, QH * 128), sentinel, device=d))
+    a = hb.AttnArgs()
+    a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_SELF, (0 if kvd == "f32" else 1), KVH, 4, R, T
+    a.q, a.ldq, a.q_off, a.k_off, a.v_off = hb.ptr(qkv), nq, 0, QH * 128, (QH + KVH) * 128
+    a.kc, a.vc, a.cur = hb.ptr(kc), hb.ptr(vc), hb.ptr(curs)
+    a.cos_t, a.sin_t = hb.ptr(cos), hb.ptr(sin)
+    a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(P), P[0].numel(), P.shape[2]
+    scr = torch.zeros(hb.lib().dia_attn_scratch_floats(R, KVH, T), device=d)
+    tk = torch.zeros(R * KVH, dtype=torch.int32, device=d)
+    a.scratch, a.tickets, a.head_map, a.v_blocked = hb.ptr(scr), hb.ptr(tk), hb.ptr(hmap), int(blocked)
+    hb.check(hb.lib().dia_attn(C.byref(a), None), "dia_attn")
+    torch.cuda.synchronize()
+    if blocked:
+        vc = lay.v_from_blocked(vc)
+    out = lay.unpack_planes(P, mt * 16, QH * 128).double().reshape(mt * 16, QH, 128)
+
+    def rope(x, pos):
+        c, s = cos[pos].double(), sin[pos].double()
+        return torch.cat([x[..., :64] * c - x[..., 64:] * s, x[..., :64] * s + x[..., 64:] * c], dim=-1)
+
+    q = rope(qkv[:, : QH * 128].double().reshape(R, QH, 128), cur)
+    worst = 0.0
+    for r in range(R):
+        for h in range(QH):
+            if not live[h]:
+                continue
+            kvh = h // 4
+            ref = attn_ref(q[r, h: h + 1], kc[r, kvh, :cur].double(), vc[r, kvh, :cur].double())
+            worst = max(worst, (out[r, int(hmap[h])] - ref[0]).abs().max().item())
+    assert worst <= 2e-5, worst
+    assert (out[:R, nl:] == sentinel).all() and (out[R:] == sentinel).all()      # head positions >= live count: not written

@@ -180,7 +180,7 @@ def test_bf16_kv_mode_mid(mid):
     worst = max(float(np.abs(logits[i][0] - r.logits[i]).max()) for i in range(len(r.logits)))
     agree = np.mean([np.array_equal(res[0].preds[1 + i], p) for i, p in enumerate(r.preds)])
     print(f"bf16-KV: logits max-abs err {worst:.3e}, per-step sample agreement {agree:.3f}")
-    assert worst <= 5e-2 and agree >= 0.8
+    assert worst <= 1e-2 and agree >= 0.9       # measured 3.5e-3 / 0.974
 
 
 def test_termination_properties(mid):
@@ -229,17 +229,29 @@ def test_dia_api_from_state_dict(mid, golden, tmp_path):
         Dia.from_pretrained(str(tmp_path), load_dac=True)           # DAC cannot be loaded offline
 
 
-def test_full_size_first_steps_vs_oracle():
-    """Dia-1.6B shapes, synthetic weights: teacher-forced logits of the first steps against the lean
-    CPU oracle (a few seconds of CPU work), then a graph-replayed run checked through the loop's
-    size-independent properties."""
+def mixed_texts(lengths, cfg):
+    """prompts that encode to exactly `lengths` byte tokens after tagging (dia_hip.tokens.synthetic_text)"""
+    from dia_hip.tokens import synthetic_text
+    return [synthetic_text(L, cfg) for L in lengths]
+
+
+@pytest.fixture(scope="module")
+def full():
+    """Dia-1.6B shapes, synthetic weights (seed 1234): device weights, the checkpoint on the host for the oracle and on
+    the device for the pruned variant"""
     cfg = C.dia_1_6b_config()
     dev = torch.device("cuda:0")
     sd_gpu = synthetic_state_dict(cfg, seed=1234, std=0.02, device=dev)
     w = DeviceWeights(cfg, sd_gpu, dev)
     sd = {k: v.cpu() for k, v in sd_gpu.items()}
-    del sd_gpu
-    torch.cuda.empty_cache()
+    return cfg, sd, w, sd_gpu
+
+
+def test_full_size_first_steps_vs_oracle(full):
+    """Dia-1.6B shapes, synthetic weights: teacher-forced logits of the first steps against the lean
+    CPU oracle (a few seconds of CPU work), then a graph-replayed run checked through the loop's
+    size-independent properties."""
+    cfg, sd, w, _ = full
     steps = 4
     mt = steps + 1
     r, nz = oracle_run(cfg, sd, TEXTS[0], 42, mt, max_steps=steps)
@@ -264,19 +276,16 @@ def test_full_size_first_steps_vs_oracle():
     prompt = np.random.RandomState(2).randint(0, 1024, size=(100, 9)).astype(np.int32)
     ids = [encode_text(effective_text(TEXTS[1], "[S1] The prompt."), cfg)]
     firsts = []
-    for replay in ("0", "1"):
-        os.environ["DIA_PROMPT_REPLAY"] = replay
-        try:
-            s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=110, seeds=[1], audio_prompts=[prompt], ignore_eos=True)
-            s.prefill(); s.sync()
-            assert s._prompt_prefill_batched() == (replay == "0")
-            s.decode(101 - int(s.cur[0].item()) + 1, use_graph=False)          # up to and including step 101 = first_step
-            s.sync()
-            assert int(s.cur[0].item()) == 102
-            firsts.append(s.logits_host()[0].copy())
-            s.close()
-        finally:
-            os.environ.pop("DIA_PROMPT_REPLAY", None)
+    for replay in (False, True):
+        s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=110, seeds=[1], audio_prompts=[prompt], ignore_eos=True,
+                          prompt_prefill="replay" if replay else "auto")
+        s.prefill(); s.sync()
+        assert s._prompt_prefill_batched() == (not replay)
+        s.decode(101 - int(s.cur[0].item()) + 1, use_graph=False)          # up to and including step 101 = first_step
+        s.sync()
+        assert int(s.cur[0].item()) == 102
+        firsts.append(s.logits_host()[0].copy())
+        s.close()
     err = float(np.abs(firsts[0] - firsts[1]).max())
     print(f"Dia-1.6B audio prompt (100 frames): first sampled logits, batched prefill vs replay: {err:.3e}")
     assert err <= 2e-2
@@ -460,7 +469,7 @@ def test_callers_cli_adapter_and_chunk_chain(mid, tmp_path):
     assert CL.generate_long.__doc__ and dia.dac_model is None
 
 
-def test_audio_prompt_batched_prefill_bf16(mid, monkeypatch):
+def test_audio_prompt_batched_prefill_bf16(mid):
     """bf16 caches: the prompt rows run as one packed batch through the MFMA-tiled GEMMs and the
     dia_dec_prefill_* kernels instead of being replayed step by step.  Same semantics: caches and the logits of
     the first sampled step agree with the replay to bf16-cache accuracy, and with the fp32 oracle within the
@@ -477,11 +486,8 @@ def test_audio_prompt_batched_prefill_bf16(mid, monkeypatch):
     ids = [encode_text(effective_text(t, pt), cfg) for t, pt in zip(texts, ptexts)]
 
     def first_logits(replay):
-        if replay:
-            monkeypatch.setenv("DIA_PROMPT_REPLAY", "1")
-        else:
-            monkeypatch.delenv("DIA_PROMPT_REPLAY", raising=False)
-        s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=mt, noise=torch.stack(nzs), audio_prompts=prompts)
+        s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=mt, noise=torch.stack(nzs), audio_prompts=prompts,
+                          prompt_prefill="replay" if replay else "auto")
         assert s.first_steps == [8, 1, 46, 2]
         s.prefill(); s.sync()
         assert s._prompt_prefill_batched() == (not replay)
@@ -546,3 +552,142 @@ def test_structured_pruned_odd_ratios_match_oracle(mid, amount):
     s.prefill(); s.run(use_graph=True, poll=8)
     out = s.results()[0]; s.close()
     assert np.array_equal(out.tokens, r.tokens)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The configurations bench.py measures (BASELINE configs 2-4), each against per-utterance oracle runs.
+# ---------------------------------------------------------------------------------------------------
+MID_LENS = [20, 33, 64, 97, 128, 160, 200, 250, 45, 77]
+
+
+@pytest.mark.parametrize("B", [3, 8, 10])
+def test_pruned_compacted_batched_vs_oracle(mid, B):
+    """BASELINE config 4 on the mid model: 50 % structured-pruned (pruning_utils.py:64-151 defaults of
+    offline_prune.py), compacted, batches of mixed text lengths — 6 rows (k_gemm16 with cmap / strip_map /
+    head_map), 16 rows (the full m-tile) and 20 rows (two m-tiles).  Every utterance == its own oracle run on the
+    same zero-holding checkpoint: teacher-forced logits <= 1e-3 and samples exact (eager), free-running token
+    buffers identical (graph replay)."""
+    from dia_hip.pruning import structured_prune_state_dict
+    cfg, sd, _ = mid
+    psd, _ = structured_prune_state_dict(cfg, sd, amount=0.5, dim=0, n=2)
+    wc = DeviceWeights(cfg, psd, torch.device("cuda:0"))
+    assert wc.compacted
+    mt = 24
+    texts = mixed_texts(MID_LENS[:B], cfg)
+    seeds = [42 + 5 * b for b in range(B)]
+    runs = [oracle_run(cfg, psd, t, sd_, mt) for t, sd_ in zip(texts, seeds)]
+    assert [len(encode_text(effective_text(t), cfg)) for t in texts] == MID_LENS[:B]
+    logits, res = teacher_forced(wc, cfg, texts, [r.tokens for r, _ in runs], [nz for _, nz in runs], mt)
+    worst = 0.0
+    for b, (r, _) in enumerate(runs):
+        for i in range(len(r.logits)):
+            worst = max(worst, float(np.abs(logits[i][b] - r.logits[i]).max()))
+        for i, p in enumerate(r.preds):
+            assert np.array_equal(res[b].preds[1 + i], p), (b, i)
+    print(f"pruned+compacted batch {B}: teacher-forced logits max-abs err {worst:.3e}")
+    assert worst <= LOGIT_TOL
+    ids = [encode_text(effective_text(t), cfg) for t in texts]
+    for use_graph in (True, False):
+        s = DecodeSession(wc, ids, kv_dtype="f32", max_tokens=mt, seeds=seeds)
+        s.prefill(); s.run(use_graph=use_graph, poll=8)
+        out = s.results(); s.close()
+        for b, (r, _) in enumerate(runs):
+            assert np.array_equal(out[b].tokens, r.tokens), (use_graph, b)
+            assert out[b].last_step == r.last_step
+
+
+def test_pruned_compacted_audio_prompt_batched(mid):
+    """compacted decoder + audio prompts of mixed lengths in one batch (prompt rows replayed or prefilled as a packed
+    batch, whichever the session picks): tokens identical to the oracle on the pruned checkpoint."""
+    from dia_hip.pruning import structured_prune_state_dict
+    cfg, sd, _ = mid
+    psd, _ = structured_prune_state_dict(cfg, sd, amount=0.5, dim=0, n=2)
+    wc = DeviceWeights(cfg, psd, torch.device("cuda:0"))
+    dm = O.Dims.of(cfg)
+    rs = np.random.RandomState(3)
+    prompts = [rs.randint(0, 1024, size=(9, dm.C)).astype(np.int32), None, rs.randint(0, 1024, size=(21, dm.C)).astype(np.int32)]
+    ptexts = ["[S1] A prompt transcript.", None, "[S2] Another one, a bit longer."]
+    mt, seeds = 48, [42, 7, 123]
+    torch.set_num_threads(cpu_threads())
+    runs = []
+    for t, p, pt, sd_ in zip(TEXTS, prompts, ptexts, seeds):
+        nz = O.exp_noise(sd_, mt - 1, dm.C, dm.tgt_vocab)
+        runs.append((O.generate(psd, cfg, t, max_tokens=mt, noise=nz, mirror=False, audio_prompt=p, audio_prompt_text=pt), nz))
+    ids = [encode_text(effective_text(t, pt), cfg) for t, pt in zip(TEXTS, ptexts)]
+    s = DecodeSession(wc, ids, kv_dtype="f32", max_tokens=mt, noise=torch.stack([nz for _, nz in runs]), audio_prompts=prompts)
+    s.prefill(); s.run(use_graph=True, poll=8)
+    out = s.results(); s.close()
+    for b, (r, _) in enumerate(runs):
+        assert np.array_equal(out[b].tokens, r.tokens), b
+
+
+FULL_LENS = [32, 64, 96, 128, 192, 256, 384, 512]      # SURVEY.md §8d: batch-8 mixed lengths, sum 1664
+
+
+@pytest.mark.parametrize("pruned", [False, True])
+def test_full_size_batch8_mixed_vs_oracle(full, pruned):
+    """BASELINE configs 3 and 4 at Dia-1.6B shapes: batch 8 with text lengths 32..512, dense and 50 %-structured-pruned
+    + compacted; three teacher-forced steps per utterance against the lean oracle (the persistent multi-strip GEMM
+    forms, split-K 4 on wo and the packed 1664-row prefill only exist at this size)."""
+    cfg, sd, w, sd_gpu = full
+    if pruned:
+        from dia_hip.pruning import structured_prune_state_dict
+        psd_gpu, _ = structured_prune_state_dict(cfg, sd_gpu, amount=0.5, dim=0, n=2)
+        w = DeviceWeights(cfg, psd_gpu, torch.device("cuda:0"))
+        assert w.compacted
+        sd = {k: v.cpu() for k, v in psd_gpu.items()}
+        del psd_gpu
+    steps = 3
+    mt = steps + 1
+    texts = mixed_texts(FULL_LENS, cfg)
+    ids = [encode_text(effective_text(t), cfg) for t in texts]
+    assert [len(i) for i in ids] == FULL_LENS
+    seeds = [42 + b for b in range(8)]
+    runs = [oracle_run(cfg, sd, t, sd_, mt, max_steps=steps) for t, sd_ in zip(texts, seeds)]
+    logits, res = teacher_forced(w, cfg, texts, [r.tokens for r, _ in runs], [nz[: mt - 1] for _, nz in runs], mt)
+    worst = 0.0
+    for b, (r, _) in enumerate(runs):
+        for i in range(len(r.logits)):
+            worst = max(worst, float(np.abs(logits[i][b] - r.logits[i]).max()))
+        for i, p in enumerate(r.preds):
+            assert np.array_equal(res[b].preds[1 + i], p), (b, i)
+    print(f"Dia-1.6B batch 8 mixed{' pruned-50 compacted' if pruned else ''}: {steps} teacher-forced steps, logits max-abs err {worst:.3e}")
+    assert worst <= LOGIT_TOL
+    # graph replay == eager, bitwise, in the perf configuration (bf16 K/V)
+    outs = []
+    for use_graph in (False, True):
+        s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=20, seeds=seeds, ignore_eos=True)
+        s.prefill(); s.run(use_graph=use_graph)
+        outs.append((np.stack([r_.tokens for r_ in s.results()]), s.logits_host().copy()))
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+BF16_KV_LOGIT_BOUND_FULL = 4e-2      # measured on MI355X: 1.94e-2 over 40 steps, 90 % of the samples identical, first
+                                     # free-running divergence at row 32; fp32 K/V is the configuration that meets 1e-3
+
+
+def test_full_size_bf16_kv_vs_oracle(full):
+    """The perf configuration (bf16 K/V caches = the reference's GPU bf16 cache, state.py:142-151) at Dia-1.6B size
+    against the fp32 oracle: 40 teacher-forced steps (logits error, per-step sample agreement) and the length of the
+    identical prefix of a free-running generation.  What bf16 K/V costs is recorded here; fp32 K/V meets 1e-3."""
+    cfg, sd, w, _ = full
+    steps = 40
+    mt = steps + 1
+    r, nz = oracle_run(cfg, sd, TEXTS[0], 42, mt, max_steps=steps)
+    out = {}
+    for kv in ("f32", "bf16"):
+        logits, res = teacher_forced(w, cfg, [TEXTS[0]], [r.tokens], [nz[: mt - 1]], mt, kv=kv)
+        worst = max(float(np.abs(logits[i][0] - r.logits[i]).max()) for i in range(len(r.logits)))
+        agree = float(np.mean([np.array_equal(res[0].preds[1 + i], p) for i, p in enumerate(r.preds)]))
+        ids = [encode_text(effective_text(TEXTS[0]), cfg)]
+        s = DecodeSession(w, ids, kv_dtype=kv, max_tokens=mt, noise=nz[None, : mt - 1])
+        s.prefill(); s.run(use_graph=True, poll=16)
+        free = s.results()[0]; s.close()
+        same = (free.tokens[:mt] == r.tokens[:mt]).all(axis=1)
+        prefix = int(np.argmin(same)) if not same.all() else mt
+        out[kv] = (worst, agree, prefix)
+        print(f"Dia-1.6B {kv} K/V vs fp32 oracle: {steps} teacher-forced steps logits max-abs err {worst:.3e}, "
+              f"sample agreement {agree:.3f}, free-running identical rows {prefix}/{mt}")
+    assert out["f32"][0] <= LOGIT_TOL and out["f32"][1] == 1.0 and out["f32"][2] == mt
+    assert out["bf16"][0] <= BF16_KV_LOGIT_BOUND_FULL and out["bf16"][1] >= 0.8
