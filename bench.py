@@ -4,10 +4,16 @@
     python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
 
 A "step" is one decode step of the whole batch (one frame per utterance = 9 codebook tokens).
-Workload at N=1: BASELINE.json configs[1] — Dia-1.6B shapes, bf16 weights + bf16 K/V, batch 1,
-1024 decode steps, synthetic seeded weights (no checkpoint exists offline), README prompt.
-Everything is resident in HBM before the timed region; the loop replays one hipGraph per step and
-never syncs with the host inside the region.  Prints ONE JSON line (rank 0).
+Workload (BASELINE.json):
+  N = 1   configs[1] — Dia-1.6B shapes, bf16 weights + bf16 K/V, batch 1, 1024 decode steps, README prompt.
+          The same run also measures, at 1024 steps each whatever --steps says, every other single-GPU
+          configuration of BASELINE.json (`configs` object of the JSON line): batch 1 with fp32 K/V (the
+          configuration that meets the 1e-3 logit parity bound), batch 8 mixed text lengths 32..512 (configs[2]),
+          and the 50 %-structured-pruned, compacted checkpoint at batch 8 and batch 1 (configs[3]).
+  N > 1   configs[4] — 64 utterances in all, 64/N per GPU (mixed lengths), weights broadcast once from rank 0.
+Synthetic seeded weights (no checkpoint exists offline).  Everything is resident in HBM before the timed
+region; the loop replays one hipGraph per step and never syncs with the host inside the region.
+Prints ONE JSON line (rank 0).
 """
 
 from __future__ import annotations
@@ -26,10 +32,17 @@ import numpy as np
 import torch
 
 PROMPT = "[S1] Dia is an open weights text to dialogue model. [S2] You get full control over scripts and voices."
-MIXED_L = [32, 64, 96, 128, 192, 256, 384, 512]
+MIXED_L = [32, 64, 96, 128, 192, 256, 384, 512]      # batch-8 mixed lengths, sum 1664
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, same guide
 FRAME_RATE = 44100.0 / 512.0   # 86.13 frames per second of audio
 LAUNCH_NAMES = ["qkv", "attn_self", "o", "cq", "attn_cross", "co", "wi", "wo"]
+TOTAL_UTTERANCES_MULTI_GPU = 64   # BASELINE.json configs[4]
+
+
+def default_batch(world: int) -> int:
+    """utterances per GPU when --batch is not given: BASELINE configs[1] on one GPU, configs[4] (64 in all) on N"""
+    return 1 if world == 1 else max(1, TOTAL_UTTERANCES_MULTI_GPU // world)
 
 
 def cpu_threads() -> int:
@@ -48,19 +61,152 @@ def texts_for(batch: int, cfg):
     return [synthetic_text(MIXED_L[i % len(MIXED_L)], cfg) for i in range(batch)]
 
 
+def launch_bytes(sess, w, n_keys: int):
+    """algorithmic HBM bytes of every launch of one decode step, in launch order: the matrix a GEMV
+    streams, the K/V an attention launch reads (self: both CFG rows of every utterance at length n_keys; cross: the cond
+    rows' text keys), the logits head; the sampler reads the logits it is handed (L2-resident: 0)"""
+    d = sess.cfg.model.decoder
+    kvb = 4 if sess.kv_code == 0 else 2
+    kv_self = 2 * sess.R * d.kv_heads * 128 * kvb * n_keys
+    kv_cross = 2 * d.cross_query_heads * 128 * kvb * sum(sess.lens)
+    out = []
+    for L in w.dec_layers:
+        out += [L["qkv"].nbytes, kv_self, L["o"].nbytes, L["cq"].nbytes, kv_cross, L["co"].nbytes, L["wi"].nbytes, L["wo"].nbytes]
+    out += [w.logits.nbytes, 0]
+    return out
+
+
+def kernel_table(sess, w, reps: int):
+    """Per kernel instantiation: launches per step, mean duration (dispatch-level begin/end timestamps of `reps` eager
+    steps chained behind a device-side delay = what rocprofv3 --kernel-trace reports), mean algorithmic bytes, GB/s."""
+    names, ms = None, []
+    for _ in range(reps):
+        t = sess.time_step()
+        names = sess.last_kernel_names
+        ms.append(t)
+    ms = np.stack(ms)                                   # [reps, launches]
+    n_keys = int(sess.cur.max().item())
+    byts = launch_bytes(sess, w, n_keys)
+    nl = sess.cfg.model.decoder.n_layer
+    ops = [LAUNCH_NAMES[i % 8] for i in range(nl * 8)] + ["logits", "sample_fsm_embed"]
+    step_us = float(ms.sum(axis=1).mean() * 1e3)
+    tab = {}
+    for i, nm in enumerate(names):
+        e = tab.setdefault(nm, {"launches_per_step": 0, "us": 0.0, "bytes": 0.0, "ops": set()})
+        e["launches_per_step"] += 1
+        e["us"] += float(ms[:, i].mean() * 1e3)
+        e["bytes"] += byts[i] if i < len(byts) else 0
+        e["ops"].add(ops[i] if i < len(ops) else "?")
+    rows = []
+    for nm, e in tab.items():
+        n = e["launches_per_step"]
+        us, b = e["us"] / n, e["bytes"] / n
+        rows.append({"kernel": nm, "ops": sorted(e["ops"]), "launches_per_step": n, "us_per_launch": round(us, 3),
+                     "bytes_per_launch": int(b), "achieved": round(b / (us * 1e-6) / 1e9, 1) if us > 0 else 0.0,
+                     "frac": round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else 0.0,
+                     "share_of_kernel_time": round(e["us"] / step_us, 4)})
+    rows.sort(key=lambda r: -r["share_of_kernel_time"])
+    per_op = {}
+    for i, o in enumerate(ops[: ms.shape[1]]):
+        per_op.setdefault(o, []).append(float(ms[:, i].mean() * 1e3))
+    per_op = {o: round(float(np.mean(v)), 3) for o, v in per_op.items()}
+    return rows, per_op, step_us
+
+
+def measure(w, cfg, *, batch, kv, steps, warmup, use_graph=True, seeds=None, dist=None, dev=None, profile_reps=0):
+    """One configuration: session, prefill (warm pass timed on the GPU), `warmup` untimed + `steps` timed decode steps
+    between barriers; returns the numbers of the JSON line for it."""
+    from dia_hip.engine import DecodeSession
+    from dia_hip.tokens import effective_text, encode_text
+
+    texts = texts_for(batch, cfg)
+    ids = [encode_text(effective_text(t), cfg) for t in texts]
+    max_tokens = 1 + warmup + steps + profile_reps + 2
+    if max_tokens > cfg.data.audio_length:
+        raise SystemExit(f"warmup+steps must stay below audio_length={cfg.data.audio_length}")
+    sess = DecodeSession(w, ids, kv_dtype=kv, max_tokens=max_tokens, seeds=seeds or [42 + i for i in range(batch)], ignore_eos=True)
+    tp = time.time()
+    sess.prefill()
+    sess.sync()
+    prefill_s = time.time() - tp
+    # second, warm pass bracketed by events on the session's stream: GPU-side prefill time (the first pass pays
+    # module loading and allocator growth), for the MFMA utilisation of the prefill GEMMs (north star)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(sess.stream)
+    sess.prefill()
+    ev1.record(sess.stream)
+    sess.sync()
+    prefill_gpu_s = ev0.elapsed_time(ev1) * 1e-3
+    e_ = cfg.model.encoder
+    rows_ = sum(sess.lens)
+    prefill_params = w.prefill_weight_bytes() / 2.0          # encoder + cross-K/V matrices as loaded (compacted if pruned)
+    attn_flops = e_.n_layer * e_.n_head * 4 * 128 * sum(l * l for l in sess.lens)
+    prefill_flops = 2.0 * rows_ * prefill_params + attn_flops
+    alg_tflops = prefill_flops / prefill_gpu_s / 1e12
+    prefill = {"text_bytes": rows_, "gpu_s": round(prefill_gpu_s, 5), "host_s_first_call": round(prefill_s, 4),
+               "algorithmic_tflop": round(prefill_flops / 1e12, 4), "achieved_tflops_algorithmic": round(alg_tflops, 1),
+               "peak_tflops_bf16_dense": MFMA_PEAK_TFLOPS, "mfma_frac": round(alg_tflops / MFMA_PEAK_TFLOPS, 4),
+               "mfma_frac_issued": round(3 * alg_tflops / MFMA_PEAK_TFLOPS, 4),
+               "note": "mfma_frac = ALGORITHMIC flops (2*rows*params + attention) / GPU time of the whole warm prefill pass incl. the launch "
+                       "gaps of its host-driven chain / 2.5 PFLOP/s; every product is fp32-exact = 3 bf16 MFMAs (hi/mid/lo activation "
+                       "plane x bf16 weight), so the matrix pipe issues 3x that (mfma_frac_issued)"}
+
+    sess.ensure_noise(warmup + steps + profile_reps + 2)      # host RNG + upload stay outside the timed region
+    sess.decode(warmup, use_graph)
+    sess.sync()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t1 = time.perf_counter()
+    ev0.record(sess.stream)
+    sess.decode(steps, use_graph)
+    ev1.record(sess.stream)
+    sess.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t1
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    cur_after = int(sess.cur.min().item())
+    assert cur_after == 1 + warmup + steps, (cur_after, warmup, steps)        # every timed step really executed
+    n_mid = warmup + (steps + 1) / 2.0                      # whole-step algorithmic traffic at the region's mean KV length
+    step_bytes = sess.step_bytes(int(round(n_mid)))
+    step_gbs = step_bytes / (dev_ms / steps * 1e-3) / 1e9
+    out = {"batch": batch, "kv": kv, "steps": steps, "warmup": warmup, "text_bytes": list(sess.lens),
+           "elapsed_s": elapsed, "ms_per_step": round(elapsed / steps * 1e3, 4), "device_ms_per_step": round(dev_ms / steps, 4),
+           "frames_per_s": round(batch * steps / elapsed, 2), "rtf_per_utterance": round(steps / elapsed / FRAME_RATE, 3),
+           "decode_weight_bytes": int(w.decode_weight_bytes()),
+           "step_roofline": {"bytes_per_step": int(step_bytes), "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
+           "prefill": prefill}
+    if profile_reps > 0:
+        rows, per_op, step_us = kernel_table(sess, w, profile_reps)
+        out["kernels"] = rows
+        out["us_per_launch_by_op"] = per_op
+        out["kernel_time_per_step_us"] = round(step_us, 1)
+    sess.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: 1 on one GPU, 64/N on N GPUs)")
     ap.add_argument("--kv", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-steps", type=int, default=40, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--prefetch", type=int, default=0, help="weight prefetch lookahead in launches (experiment)")
+    ap.add_argument("--profile-steps", type=int, default=3, help="eager steps timed kernel by kernel for the roofline objects (0 = skip)")
     ap.add_argument("--pruned", type=float, default=0.0, help="structured dim-0 pruning amount applied to the synthetic checkpoint (BASELINE config 4: 0.5)")
     ap.add_argument("--no-compact", action="store_true", help="with --pruned: stream the zeros instead of compacting")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (the other single-GPU BASELINE configurations)")
+    ap.add_argument("--config-steps", type=int, default=1024, help="decode steps of each `configs` entry")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,25 +232,25 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from dia_hip import config as C
-    from dia_hip.engine import DecodeSession, DeviceWeights
-    from dia_hip.tokens import effective_text, encode_text
+    from dia_hip.engine import DeviceWeights
     from dia_hip.weights import synthetic_state_dict
     from dia_hip.dist import broadcast_weights
 
     cfg = C.dia_1_6b_config()
     K, Wm = args.steps, args.warmup
-    max_tokens = 1 + Wm + K + args.profile_steps + 1
-    if max_tokens > cfg.data.audio_length:
-        raise SystemExit(f"warmup+steps must stay below audio_length={cfg.data.audio_length}")
+    batch = args.batch if args.batch > 0 else default_batch(world)
+    use_graph = not args.no_graph
 
-    # ---- weights: rank 0 builds + repacks, the other ranks receive the repacked tensors over RCCL
+    # ---- weights: rank 0 builds + repacks, the other ranks receive the flat arena in ONE broadcast over RCCL
     t0 = time.time()
-    sd_gpu = synthetic_state_dict(cfg, seed=1234, std=0.02, device=dev) if (rank == 0 or args.pruned > 0) else None
+    need_sd = rank == 0 or args.pruned > 0
+    sd_gpu = synthetic_state_dict(cfg, seed=1234, std=0.02, device=dev) if need_sd else None
+    sd_run = sd_gpu
     if args.pruned > 0:
         from dia_hip.pruning import structured_prune_state_dict
-        sd_gpu, _ = structured_prune_state_dict(cfg, sd_gpu, amount=args.pruned, dim=0, n=2)     # offline_prune.py defaults
-    if rank == 0 or args.pruned > 0:
-        w = DeviceWeights(cfg, sd_gpu, dev, compact="off" if args.no_compact else "auto")
+        sd_run, _ = structured_prune_state_dict(cfg, sd_gpu, amount=args.pruned, dim=0, n=2)     # offline_prune.py defaults
+    if need_sd:
+        w = DeviceWeights(cfg, sd_run, dev, compact="off" if args.no_compact else "auto")
     else:
         w = DeviceWeights.empty_like_config(cfg, dev)
     bcast_s = 0.0
@@ -116,126 +262,88 @@ def main():
         bcast_s = time.time() - tb
     load_s = time.time() - t0
 
-    texts = texts_for(args.batch, cfg)
-    ids = [encode_text(effective_text(t), cfg) for t in texts]
-    seeds = [42 + 1000 * rank + i for i in range(args.batch)]
-    sess = DecodeSession(w, ids, kv_dtype=args.kv, max_tokens=max_tokens, seeds=seeds, ignore_eos=True)
-    if args.prefetch > 0:
-        sess.set_prefetch(args.prefetch)
-    tp = time.time()
-    sess.prefill()
-    sess.sync()
-    prefill_s = time.time() - tp
-    # second, warm pass bracketed by events on the session's stream: GPU-side prefill time (the first pass pays
-    # module loading and allocator growth), for the MFMA utilisation of the prefill GEMMs (north star)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(sess.stream)
-    sess.prefill()
-    ev1.record(sess.stream)
-    sess.sync()
-    prefill_gpu_s = ev0.elapsed_time(ev1) * 1e-3
-    e_, d_ = cfg.model.encoder, cfg.model.decoder
-    rows_ = sum(sess.lens)
-    prefill_params = w.prefill_weight_bytes() / 2.0          # encoder + cross-K/V matrices as loaded (compacted if pruned)
-    attn_flops = e_.n_layer * e_.n_head * 4 * 128 * sum(l * l for l in sess.lens)
-    prefill_flops = 2.0 * rows_ * prefill_params + attn_flops
-    MFMA_PEAK_TFLOPS = 2500.0                      # dense bf16, MI355X_MICROARCH.md
-    prefill = {"text_bytes": rows_, "gpu_s": round(prefill_gpu_s, 5), "host_s_first_call": round(prefill_s, 4),
-               "algorithmic_tflop": round(prefill_flops / 1e12, 4),
-               "achieved_tflops_algorithmic": round(prefill_flops / prefill_gpu_s / 1e12, 1),
-               "mfma_tflops_issued": round(3 * prefill_flops / prefill_gpu_s / 1e12, 1),
-               "peak_tflops_bf16_dense": MFMA_PEAK_TFLOPS,
-               "mfma_frac": round(3 * prefill_flops / prefill_gpu_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
-               "note": "every product is fp32-exact = 3 bf16 MFMAs (hi/mid/lo activation plane x bf16 weight); mfma_frac counts the "
-                       "issued MFMA work over the whole prefill interval incl. launch gaps of the host-driven chain"}
+    seeds = [42 + 1000 * rank + i for i in range(batch)]
+    prof = args.profile_steps if (rank == 0) else 0
+    m = measure(w, cfg, batch=batch, kv=args.kv, steps=K, warmup=Wm, use_graph=use_graph, seeds=seeds, dist=dist, dev=dev, profile_reps=prof)
 
-    use_graph = not args.no_graph
-    sess.ensure_noise(Wm + K + args.profile_steps + 1)       # host RNG + upload stay outside the timed region
-    sess.decode(Wm, use_graph)
-    sess.sync()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t1 = time.perf_counter()
-    ev0.record(sess.stream)
-    sess.decode(K, use_graph)
-    ev1.record(sess.stream)
-    sess.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t1
-    dev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    cur_after = int(sess.cur.min().item())
-    assert cur_after == 1 + Wm + K, (cur_after, Wm, K)        # every timed step really executed
-
-    # ---- per-launch HIP-event timing of eager steps (KV length ~ Wm+K), on the engine's stream
-    prof = np.stack([sess.profile_step() for _ in range(args.profile_steps)]) if args.profile_steps > 0 else None
-    nl = cfg.model.decoder.n_layer
-    roof = None
-    breakdown = None
-    if prof is not None:
-        per = prof[:, : nl * 8].reshape(-1, nl, 8)                 # [rep, layer, kind]
-        kind_ms = per.mean(axis=(0, 1))
-        breakdown = {LAUNCH_NAMES[i]: round(float(kind_ms[i]) * 1e3, 2) for i in range(8)}
-        breakdown["logits"] = round(float(prof[:, nl * 8].mean()) * 1e3, 2)
-        breakdown["sample_fsm_embed"] = round(float(prof[:, nl * 8 + 1].mean()) * 1e3, 2)
-        breakdown["unit"] = "us between per-launch HIP events of one eager step (each interval carries ~3 us of event/boundary overhead)"
-        wi_ms = sess.time_wi_launches(reps=5) * 1e3          # dispatch-level start/stop events per launch
-        wi_bytes = sum(L["wi"].nbytes for L in w.dec_layers) / len(w.dec_layers)   # algorithmic bytes of the dominant kernel
-        rows = 2 * args.batch
-        wi_k, wi_n = w.dec_layers[0]["wi"].kt * 32, w.dec_layers[0]["wi"].ns * 16
-        # the dispatcher's choice for this shape (dia_gemm in gemm.hip); rocprofv3's kernel name in
-        # profiles/ is the authority
-        if rows <= 4:
-            kname = "k_gemv_small<NW=16,KPW=%d,RS=%d,MULTI>" % (wi_k // 32 // 16, 2 if rows <= 2 else 4)
-        elif rows <= 16:
-            kname = "k_gemm16<NW=8,KPW=%d,MULTI>" % (wi_k // 32 // 8)
-        else:
-            kname = "k_gemm<MT=%d,NW=4,KPW=%d>" % (min(4, (rows + 15) // 16), wi_k // 32 // 4)
-        roof = {"bound": "hbm", "kernel": kname + " on wi_fused [%d x %d] bf16 (SwiGLU epilogue), 18 launches/step" % (wi_k, wi_n),
-                "achieved": round(wi_bytes / (wi_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(wi_bytes / (wi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "bytes_per_launch": wi_bytes, "us_per_launch": round(wi_ms * 1e3, 2), "traffic": None}
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled
-        # as the gfx950 guide prescribes); measured offline, committed under profiles/
-        tr = os.path.join(ROOT, "profiles", "traffic_wi.json")
-        if os.path.isfile(tr) and args.batch == 1 and not args.pruned:      # measured for exactly this kernel and shape
-            try:
-                roof["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
-
-    frames = world * args.batch * K
-    value = frames / elapsed
-    ms_per_step = elapsed / K * 1e3
-    # whole-step algorithmic traffic, averaged over the timed region's KV lengths
-    n_mid = Wm + (K + 1) / 2.0
-    step_bytes = sess.step_bytes(int(round(n_mid)))
-    step_gbs = step_bytes / (dev_ms / K * 1e-3) / 1e9
-
+    frames = world * batch * K
+    value = frames / m["elapsed_s"]
+    pruned_txt = f" {round(args.pruned * 100)}%-structured-pruned (dim 0, compacted={not args.no_compact})" if args.pruned else ""
+    if world > 1:
+        workload = (f"Dia-1.6B{pruned_txt} bf16 weights, {args.kv} K/V, {world * batch} utterances sharded data-parallel over {world} GPUs "
+                    f"({batch} per GPU, mixed text lengths 32..512), {K} decode steps, weights broadcast once from rank 0 "
+                    f"(one flat {w.flat.numel() / 1e9:.2f} GB buffer), no per-step collective")
+    else:
+        workload = (f"Dia-1.6B{pruned_txt} bf16 weights, {args.kv} K/V, batch {batch}, {K} decode steps, text bytes {m['text_bytes']}")
+    workload += f", cfg 3.0 / T 1.3 / top-p 0.95 / top-k 35, hipGraph={use_graph}"
     out = {
         "metric": "audio-codec frames/sec (Dia-1.6B decode, whole job)", "value": round(value, 2), "unit": "frames/s",
-        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"Dia-1.6B{' %d%%-structured-pruned (dim 0, compacted=%s)' % (round(args.pruned * 100), not args.no_compact) if args.pruned else ''} bf16 weights, {args.kv} K/V, batch {args.batch} per GPU, {K} decode steps, "
-                               f"text bytes {sess.lens}, cfg 3.0 / T 1.3 / top-p 0.95 / top-k 35, hipGraph={use_graph}",
-                   "batch_per_gpu": args.batch, "parallelism": f"dp{world}" if world > 1 else "single"},
-        "frames_per_s_per_gpu": round(value / world, 2), "rtf_per_gpu": round(value / world / args.batch / FRAME_RATE, 3),
+        "config": {"workload": workload, "batch_per_gpu": batch, "parallelism": f"dp{world}" if world > 1 else "single"},
+        "frames_per_s_per_gpu": round(value / world, 2), "rtf_per_gpu": round(value / world / batch / FRAME_RATE, 3),
         "rtf_aggregate": round(value / FRAME_RATE, 2),
-        "prefill_s": round(prefill_s, 4), "prefill": prefill, "weights_load_s": round(load_s, 2), "weights_bcast_s": round(bcast_s, 3),
-        "device_ms_per_step": round(dev_ms / K, 4), "decode_weight_bytes": int(w.decode_weight_bytes()),
-        "step_roofline": {"bytes_per_step": int(step_bytes), "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
-        "launch_breakdown": breakdown,
+        "prefill_s": m["prefill"]["host_s_first_call"], "prefill": m["prefill"], "weights_load_s": round(load_s, 2),
+        "weights_bcast_s": round(bcast_s, 3),
+        "device_ms_per_step": m["device_ms_per_step"], "decode_weight_bytes": m["decode_weight_bytes"],
+        "step_roofline": m["step_roofline"],
     }
-    if roof is not None:
-        out["roofline"] = roof
+    if "kernels" in m:
+        rows = m["kernels"]
+        top = dict(rows[0])
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the gfx950 guide
+        # prescribes) cannot be collected from inside this process; they are measured by scratch/profile_round.sh on the
+        # same command and committed under profiles/ keyed by kernel name
+        traffic, src = None, None
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.isfile(tr) and not args.pruned:
+            try:
+                ent = json.load(open(tr)).get(f"batch{batch}", {}).get(top["kernel"])
+                if ent:
+                    traffic, src = ent["hbm_bytes_per_launch"], ent.get("source")
+            except Exception:
+                pass
+        out["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "ops": top["ops"], "launches_per_step": top["launches_per_step"],
+                           "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"],
+                           "bytes_per_launch": top["bytes_per_launch"], "us_per_launch": top["us_per_launch"],
+                           "share_of_kernel_time": top["share_of_kernel_time"], "traffic": traffic, "traffic_source": src,
+                           "how": "dominant kernel BY TIME of the decode step; us = mean begin->end timestamp of the dispatch packet over "
+                                  f"{args.profile_steps} eager steps chained behind a device-side delay (the duration rocprofv3 "
+                                  "--kernel-trace reports); bytes = mean algorithmic bytes of its launches (SURVEY.md §8d)"}
+        out["roofline_by_kernel"] = rows
+        out["us_per_launch_by_op"] = m["us_per_launch_by_op"]
+        out["kernel_time_per_step_us"] = m["kernel_time_per_step_us"]
+
+    # ---- the other single-GPU configurations of BASELINE.json, 1024 steps each whatever --steps says
+    if rank == 0 and world == 1 and not args.no_configs and not args.pruned and args.batch in (0, 1) and args.kv == "bf16":
+        cs = args.config_steps
+        cfgs = {}
+
+        def brief(r, name):
+            return {"workload": name, "frames_per_s": r["frames_per_s"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                    "rtf_per_utterance": r["rtf_per_utterance"], "decode_weight_bytes": r["decode_weight_bytes"],
+                    "step_bytes": r["step_roofline"]["bytes_per_step"], "step_frac_of_hbm_peak": r["step_roofline"]["frac"],
+                    "prefill_gpu_ms": round(r["prefill"]["gpu_s"] * 1e3, 2), "prefill_mfma_frac": r["prefill"]["mfma_frac"]}
+
+        if K == cs and Wm == 16:
+            cfgs["batch1_bf16kv"] = brief(m, "BASELINE configs[1]: batch 1, bf16 K/V (= the headline line)")
+        else:
+            cfgs["batch1_bf16kv"] = brief(measure(w, cfg, batch=1, kv="bf16", steps=cs, warmup=16), "BASELINE configs[1]: batch 1, bf16 K/V")
+        cfgs["batch1_f32kv"] = brief(measure(w, cfg, batch=1, kv="f32", steps=cs, warmup=16),
+                                     "batch 1, fp32 K/V: the configuration whose logits meet 1e-3 against the fp32 reference path")
+        cfgs["batch8_mixed_bf16kv"] = brief(measure(w, cfg, batch=8, kv="bf16", steps=cs, warmup=16),
+                                            "BASELINE configs[2]: batch 8, text bytes 32..512 (sum 1664), bf16 K/V")
+        cfgs["batch8_mixed_f32kv"] = brief(measure(w, cfg, batch=8, kv="f32", steps=cs, warmup=16), "batch 8 mixed, fp32 K/V (parity configuration)")
+        from dia_hip.pruning import structured_prune_state_dict
+        psd, _ = structured_prune_state_dict(cfg, sd_gpu, amount=0.5, dim=0, n=2)
+        wp = DeviceWeights(cfg, psd, dev)
+        del psd
+        cfgs["pruned50_batch8_bf16kv"] = brief(measure(wp, cfg, batch=8, kv="bf16", steps=cs, warmup=16),
+                                               "BASELINE configs[3]: 50 %-structured-pruned (offline_prune.py defaults), compacted, batch 8 mixed")
+        cfgs["pruned50_batch1_bf16kv"] = brief(measure(wp, cfg, batch=1, kv="bf16", steps=cs, warmup=16), "same checkpoint, batch 1")
+        del wp
+        torch.cuda.empty_cache()
+        out["configs"] = cfgs
 
     # ---- CPU baseline: the oracle in mirror mode (= the reference's op sequence incl. its dead
     #      cross-K/V work), fp32, same weights/prompt/seed, bounded sample, rank 0 at N=1 only
@@ -257,7 +365,6 @@ def main():
         }
     if rank == 0:
         print(json.dumps(out))
-    sess.close()
     if dist is not None:
         dist.destroy_process_group()
 

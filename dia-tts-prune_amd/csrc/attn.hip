@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
+#include "launch.hpp"
 #include "tuning.hpp"
 #include <cstdlib>
 
@@ -805,13 +806,13 @@ __global__ void k_enc_kv_prep(const float* qkv, int ldq, int k_off, int v_off, i
 
 template <typename KVT, int G>
 int launch_attn(const AttnK& k, int grid_y, int grid_z, hipStream_t st) {
-  hipLaunchKernelGGL((k_attn<KVT, G>), dim3(k.n_kv_heads, grid_y, grid_z), dim3(NT), 0, st, k);
+  dia_launch<k_attn<KVT, G>>(dim3(k.n_kv_heads, grid_y, grid_z), dim3(NT), 0, st, k);
   return dia_check_launch("k_attn");
 }
 
 template <int G>
 int launch_attn_mfma(const AttnK& k, int grid_y, int grid_z, hipStream_t st) {
-  hipLaunchKernelGGL((k_attn_mfma<G>), dim3(k.n_kv_heads, grid_y, grid_z), dim3(NT), 0, st, k);
+  dia_launch<k_attn_mfma<G>>(dim3(k.n_kv_heads, grid_y, grid_z), dim3(NT), 0, st, k);
   return dia_check_launch("k_attn_mfma");
 }
 
@@ -903,7 +904,7 @@ extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
 extern "C" int dia_enc_kv_prep(const float* qkv, int ldq, int k_off, int v_off, int heads, int L, int cap,
                                const float* cos_t, const float* sin_t, float* kc, float* vc, void* stream) {
   if (!qkv || !kc || !vc || !cos_t || !sin_t || heads <= 0 || L <= 0 || L > cap) return dia_fail(DIA_E_ARG, "dia_enc_kv_prep: bad argument");
-  hipLaunchKernelGGL(k_enc_kv_prep, dim3(heads, L), dim3(64), 0, (hipStream_t)stream, qkv, ldq, k_off, v_off, heads, L, cap, cos_t, sin_t, kc, vc);
+  dia_launch<k_enc_kv_prep>(dim3(heads, L), dim3(64), 0, (hipStream_t)stream, qkv, ldq, k_off, v_off, heads, L, cap, cos_t, sin_t, kc, vc);
   return dia_check_launch("k_enc_kv_prep");
 }
 
@@ -917,9 +918,9 @@ extern "C" int dia_enc_attn(const dia_enc_attn_args* a, void* stream) {
   k.row_b = a->row_b; k.seg_off = a->seg_off; k.seg_len = a->seg_len; k.cos_t = a->cos_t; k.sin_t = a->sin_t;
   k.kp = (bf16_raw*)a->kp; k.vp = (bf16_raw*)a->vp; k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_enc_kv_planes, dim3(a->heads, a->rows / 32), dim3(256), 0, st, k);
+  dia_launch<k_enc_kv_planes>(dim3(a->heads, a->rows / 32), dim3(256), 0, st, k);
   int rc = dia_check_launch("k_enc_kv_planes");
   if (rc) return rc;
-  hipLaunchKernelGGL(k_attn_enc_mfma, dim3(a->heads, a->rows / 16), dim3(NT), 0, st, k);
+  dia_launch<k_attn_enc_mfma>(dim3(a->heads, a->rows / 16), dim3(NT), 0, st, k);
   return dia_check_launch("k_attn_enc_mfma");
 }

@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
+#include "launch.hpp"
 #include "tuning.hpp"
 #include <cstdlib>
 #include <vector>
@@ -310,7 +311,7 @@ extern "C" int dia_engine_profile_step(dia_engine* e, float* ms, int cap) {
   // host has queued every launch and event, and the intervals are device-side kernel time + the
   // in-queue dependency gap (what a graph replay pays), not host launch latency.
   int rc = DIA_OK;
-  hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, e->stream, 300000LL /* 100 MHz ticks = 3 ms */);
+  dia_launch<k_delay>(dim3(1), dim3(64), 0, e->stream, 300000LL /* 100 MHz ticks = 3 ms */);
   (void)hipEventRecord(e->prof[0], e->stream);
   rc = enqueue_step(e, true);
   {
@@ -324,6 +325,25 @@ extern "C" int dia_engine_profile_step(dia_engine* e, float* ms, int cap) {
   e->prof.clear();
   return rc;
 }
+
+// One eager step behind the same device-side delay, every kernel bracketed by its own dispatch-level start / stop
+// events (launch.hpp): ms[i] = duration of the i-th kernel of the step, in launch order, as rocprofv3 would report it.
+extern "C" int dia_engine_time_step(dia_engine* e, float* ms, int cap) {
+  if (!e || !ms) return dia_fail(DIA_E_ARG, "dia_engine_time_step: null argument");
+  const int n = e->d.n_layer * 8 + 2;
+  if (cap < n) return dia_fail(DIA_E_ARG, "dia_engine_time_step: output array too small");
+  dia_launch<k_delay>(dim3(1), dim3(64), 0, e->stream, 300000LL /* 100 MHz ticks = 3 ms */);
+  dia_recorder_arm();
+  int rc = enqueue_step(e, true);
+  const int got = dia_recorder_collect(ms, cap);
+  hipError_t he = hipStreamSynchronize(e->stream);
+  if (rc != DIA_OK) return rc;
+  if (he != hipSuccess) return dia_fail_hip(he, "dia_engine_time_step: hipStreamSynchronize");
+  return got;      // kernels launched (n, or n - 1 when the MLP ran fused), or a negative DIA_E_*
+}
+
+// kernel instantiation name ("k_gemv_small<8, 8, 2, false>") of the i-th launch of this thread's last timed step / launch
+extern "C" const char* dia_timed_kernel_name(int i) { return dia_recorder_label(i); }
 
 extern "C" int dia_engine_mlp_fused(const dia_engine* e) { return e && e->mlp_fused == 1; }
 
@@ -359,7 +379,7 @@ static int ensure_sink() {
 }
 
 int dia_prefetch_launch(const void* ptr, long nbytes, int nblocks, hipStream_t st) {
-  hipLaunchKernelGGL(k_prefetch, dim3(nblocks), dim3(256), 0, st, (const uint4*)ptr, (long)(nbytes / 16), g_sink);
+  dia_launch<k_prefetch>(dim3(nblocks), dim3(256), 0, st, (const uint4*)ptr, (long)(nbytes / 16), g_sink);
   return dia_check_launch("k_prefetch");
 }
 

@@ -563,7 +563,7 @@ __global__ __launch_bounds__((8 + NPW) * 64) void k_gemm_tile_ws(GemmK p) {
 template <int KC, int PD, int NPW>
 int launch_tile_ws(const GemmK& k, hipStream_t st) {
   const int mgroups = ((k.M + 15) / 16 + GT_MT - 1) / GT_MT;
-  launch_kernel(k_gemm_tile_ws<KC, PD, NPW>, dim3((k.nstrips + 15) / 16, mgroups), dim3((8 + NPW) * 64), gt_smem(KC, 8), st, k);
+  launch_kernel<k_gemm_tile_ws<KC, PD, NPW>>(dim3((k.nstrips + 15) / 16, mgroups), dim3((8 + NPW) * 64), gt_smem(KC, 8), st, k);
   return dia_check_launch("k_gemm_tile_ws");
 }
 
@@ -600,13 +600,13 @@ int launch_g16(const GemmK& k, hipStream_t st) {
     if (spw > 1) {      // persistent multi-strip form, with or without split-K: A fragments loaded once per workgroup
       int gx = (k.nstrips + spw - 1) / spw;
       if (mz >= 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
-      if (mz > 1) launch_small_kernel(k_gemm16<NW, KPW, true, true>, dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
-      else launch_small_kernel(k_gemm16<NW, KPW, true>, dim3(gx, sk), dim3(NW * 64), smem, st, k);
+      if (mz > 1) launch_small_kernel<k_gemm16<NW, KPW, true, true>>(dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
+      else launch_small_kernel<k_gemm16<NW, KPW, true>>(dim3(gx, sk), dim3(NW * 64), smem, st, k);
       return dia_check_launch("k_gemm16");
     }
   }
-  if (mz > 1) launch_small_kernel(k_gemm16<NW, KPW, false, true>, dim3(k.nstrips, sk, mz), dim3(NW * 64), smem, st, k);
-  else launch_small_kernel(k_gemm16<NW, KPW, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
+  if (mz > 1) launch_small_kernel<k_gemm16<NW, KPW, false, true>>(dim3(k.nstrips, sk, mz), dim3(NW * 64), smem, st, k);
+  else launch_small_kernel<k_gemm16<NW, KPW, false>>(dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
   return dia_check_launch("k_gemm16");
 }
 
@@ -638,7 +638,7 @@ int launch_g16_any(const GemmK& k, int nw, int sk, hipStream_t st, bool& handled
 template <int MT, int NW, int KPW>
 int launch(const GemmK& k, int mgroups, hipStream_t st) {
   size_t smem = sizeof(f32x4) * NW * MT * 64 + sizeof(float) * (MT * 16 * 17 + MT * 16);
-  launch_kernel(k_gemm<MT, NW, KPW>, dim3(k.nstrips, mgroups), dim3(NW * 64), smem, st, k);
+  launch_kernel<k_gemm<MT, NW, KPW>>(dim3(k.nstrips, mgroups), dim3(NW * 64), smem, st, k);
   return dia_check_launch("k_gemm");
 }
 
@@ -686,16 +686,16 @@ int launch_small(const GemmK& k, hipStream_t st) {
   const int grid = (k.nstrips + spw - 1) / spw;
   const int sk = k.KT / (NW * KPW);          // cross-workgroup split-K factor (1 = none)
   if (sk > 1) {
-    launch_small_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
+    launch_small_kernel<k_gemv_small<NW, KPW, RS, false>>(dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
     return dia_check_launch("k_gemv_small");
   }
   if (spw > 1) {
     if constexpr (KPW <= 16 && !(NW == 16 && KPW > 4))
-      launch_small_kernel(k_gemv_small<NW, KPW, RS, true>, dim3(grid), dim3(NW * 64), smem, st, k);
+      launch_small_kernel<k_gemv_small<NW, KPW, RS, true>>(dim3(grid), dim3(NW * 64), smem, st, k);
     else
-      launch_small_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+      launch_small_kernel<k_gemv_small<NW, KPW, RS, false>>(dim3(k.nstrips), dim3(NW * 64), smem, st, k);
   } else {
-    launch_small_kernel(k_gemv_small<NW, KPW, RS, false>, dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+    launch_small_kernel<k_gemv_small<NW, KPW, RS, false>>(dim3(k.nstrips), dim3(NW * 64), smem, st, k);
   }
   return dia_check_launch("k_gemv_small");
 }
@@ -881,18 +881,14 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
 
 extern "C" int dia_gemm_timed(const dia_gemm_args* a, void* stream, float* ms_out) {
   if (!ms_out) return dia_fail(DIA_E_ARG, "dia_gemm_timed: null output");
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return dia_fail(DIA_E_HIP, "hipEventCreate");
-  g_ev_start = e0; g_ev_stop = e1;
+  dia_recorder_arm();
   int rc = dia_gemm(a, stream);
-  g_ev_start = g_ev_stop = nullptr;
-  if (rc == DIA_OK) {
-    hipError_t he = hipEventSynchronize(e1);
-    if (he == hipSuccess) he = hipEventElapsedTime(ms_out, e0, e1);
-    if (he != hipSuccess) rc = dia_fail_hip(he, "dia_gemm_timed");
-  }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  return rc;
+  float ms[4] = {0.f, 0.f, 0.f, 0.f};
+  const int n = dia_recorder_collect(ms, 4);
+  if (rc != DIA_OK) return rc;
+  if (n < 1) return n < 0 ? n : dia_fail(DIA_E_STATE, "dia_gemm_timed: nothing was launched");
+  *ms_out = ms[0];
+  return DIA_OK;
 }
 
 #ifndef DIA_EXPERIMENTS

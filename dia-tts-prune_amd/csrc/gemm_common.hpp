@@ -10,10 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "tuning.hpp"
-
-// when set (dia_gemm_timed), the next launch is bracketed by these events via hipExtLaunchKernelGGL:
-// the timestamps come from the dispatch packet itself (kernel begin/end), like rocprofv3's durations
-inline thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+#include "launch.hpp"
 
 namespace {
 
@@ -25,15 +22,14 @@ namespace {
 #define DIA_WLOAD(ptr) __builtin_nontemporal_load(ptr)
 #endif
 
-template <typename Kern, typename Arg>
-void launch_kernel(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream_t st, const Arg& arg) {
-  if (g_ev_start) hipExtLaunchKernelGGL(kern, grid, block, smem, st, g_ev_start, g_ev_stop, 0, arg);
-  else hipLaunchKernelGGL(kern, grid, block, smem, st, arg);
+template <auto Kern, typename Arg>
+void launch_kernel(dim3 grid, dim3 block, size_t smem, hipStream_t st, const Arg& arg) {
+  dia_launch<Kern>(grid, block, smem, st, arg);
 }
 
 struct GemmK;
-template <typename Kern>
-void launch_small_kernel(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream_t st, const GemmK& k);
+template <auto Kern>
+void launch_small_kernel(dim3 grid, dim3 block, size_t smem, hipStream_t st, const GemmK& k);
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // plain vector: HIP's uint4 struct defeats SROA in register arrays
 
@@ -56,11 +52,9 @@ struct GemmK {
   int mz;                                  // host side only: m-tiles a k_gemm16 launch covers through gridDim.z (0/1 = one)
 };
 
-template <typename Kern>
-void launch_small_kernel(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream_t st, const GemmK& k) {
-  if (g_ev_start) hipExtLaunchKernelGGL(kern, grid, block, smem, st, g_ev_start, g_ev_stop, 0, k.A, k.a_plane_stride, k.W, k.KT, k.M, k.epi,
-                                        k.nstrips, k.out, k.ldo, k.gnext, k);
-  else hipLaunchKernelGGL(kern, grid, block, smem, st, k.A, k.a_plane_stride, k.W, k.KT, k.M, k.epi, k.nstrips, k.out, k.ldo, k.gnext, k);
+template <auto Kern>
+void launch_small_kernel(dim3 grid, dim3 block, size_t smem, hipStream_t st, const GemmK& k) {
+  dia_launch<Kern>(grid, block, smem, st, k.A, k.a_plane_stride, k.W, k.KT, k.M, k.epi, k.nstrips, k.out, k.ldo, k.gnext, k);
 }
 
 __device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v) {

@@ -387,7 +387,7 @@ int launch_sparse(const GemmK& k, hipStream_t st) {
   if (grid < 256 && k.nstrips >= 256) grid = 256;
   if (grid > k.nstrips) grid = k.nstrips;
   if ((k.nstrips + grid - 1) / grid > MAXS) return dia_fail(DIA_E_ARG, "dia_gemm: too many strips for the sparse kernel");
-  launch_kernel(k_gemv_sparse<KPW, RS, MAXS>, dim3(grid), dim3(1024), smem, st, k);
+  launch_kernel<k_gemv_sparse<KPW, RS, MAXS>>(dim3(grid), dim3(1024), smem, st, k);
   return dia_check_launch("k_gemv_sparse");
 }
 
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(512) void k_gemm32(GemmK p) {
 template <int KPW>
 int launch_g32(const GemmK& k, int sk, hipStream_t st) {
   const size_t smem = sizeof(f32x4) * 8 * 2 * 64 + sizeof(float) * (2 * 16 * 17 + 32);
-  launch_kernel(k_gemm32<KPW>, dim3(k.nstrips, sk), dim3(512), smem, st, k);
+  launch_kernel<k_gemm32<KPW>>(dim3(k.nstrips, sk), dim3(512), smem, st, k);
   return dia_check_launch("k_gemm32");
 }
 
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(512) void k_gemm32m(GemmK p) {
 int launch_g32m(const GemmK& k, int sk, hipStream_t st) {
   const size_t smem = sizeof(f32x4) * 8 * 2 * 64 + sizeof(float) * (2 * 16 * 17 + 32);
   const int gx = k.nstrips < 128 ? k.nstrips : 128;
-  launch_kernel(k_gemm32m, dim3(gx, sk), dim3(512), smem, st, k);
+  launch_kernel<k_gemm32m>(dim3(gx, sk), dim3(512), smem, st, k);
   return dia_check_launch("k_gemm32m");
 }
 
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int KR, int WS>
 int launch_blk32(const GemmK& k, hipStream_t st) {
   constexpr size_t smem = (size_t)KR * DIA_NPLANES * 2 * 64 * 16 + sizeof(float) * (8 * 2 * 16 * 17 + 32);
-  launch_kernel(k_gemm_blk32<KR, WS>, dim3((k.nstrips + 8 * WS - 1) / (8 * WS), 1, k.KT / KR), dim3(512), smem, st, k);
+  launch_kernel<k_gemm_blk32<KR, WS>>(dim3((k.nstrips + 8 * WS - 1) / (8 * WS), 1, k.KT / KR), dim3(512), smem, st, k);
   return dia_check_launch("k_gemm_blk32");
 }
 
@@ -908,7 +908,7 @@ template <int KC, int PD, int WPE, int NWT>
 int launch_tile_v(const GemmK& k, hipStream_t st) {
   const int mgroups = ((k.M + 15) / 16 + GT_MT - 1) / GT_MT;
   constexpr int SPB = (NWT / 2) * GT_WS;                 // strips per workgroup
-  launch_kernel(k_gemm_tile<KC, PD, WPE, NWT>, dim3((k.nstrips + SPB - 1) / SPB, mgroups), dim3(NWT * 64), gt_smem(KC, NWT), st, k);
+  launch_kernel<k_gemm_tile<KC, PD, WPE, NWT>>(dim3((k.nstrips + SPB - 1) / SPB, mgroups), dim3(NWT * 64), gt_smem(KC, NWT), st, k);
   return dia_check_launch("k_gemm_tile");
 }
 
@@ -1023,23 +1023,19 @@ extern "C" int dia_mlp_fused(const dia_gemm_args* wi, const dia_gemm_args* wo, i
   q.bar = barrier;
   const int kpw1 = wi->KT / 16, kpw2 = wo->KT / 32;
   hipStream_t st = (hipStream_t)stream;
-  if (kpw1 == 4 && kpw2 == 8) { launch_kernel(k_mlp_fused<4, 8>, dim3(G), dim3(1024), mlp_smem(64, 128), st, q); return dia_check_launch("k_mlp_fused"); }
-  if (kpw1 == 1 && kpw2 == 1) { launch_kernel(k_mlp_fused<1, 1>, dim3(G), dim3(1024), mlp_smem(16, 16), st, q); return dia_check_launch("k_mlp_fused"); }
+  if (kpw1 == 4 && kpw2 == 8) { launch_kernel<k_mlp_fused<4, 8>>(dim3(G), dim3(1024), mlp_smem(64, 128), st, q); return dia_check_launch("k_mlp_fused"); }
+  if (kpw1 == 1 && kpw2 == 1) { launch_kernel<k_mlp_fused<1, 1>>(dim3(G), dim3(1024), mlp_smem(16, 16), st, q); return dia_check_launch("k_mlp_fused"); }
   return dia_fail(DIA_E_ARG, "dia_mlp_fused: no instantiation for these K sizes");
 }
 
 extern "C" int dia_mlp_fused_timed(const dia_gemm_args* wi, const dia_gemm_args* wo, int32_t* barrier, void* stream, float* ms_out) {
   if (!ms_out) return dia_fail(DIA_E_ARG, "dia_mlp_fused_timed: null output");
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return dia_fail(DIA_E_HIP, "hipEventCreate");
-  g_ev_start = e0; g_ev_stop = e1;
+  dia_recorder_arm();
   int rc = dia_mlp_fused(wi, wo, barrier, stream);
-  g_ev_start = g_ev_stop = nullptr;
-  if (rc == DIA_OK) {
-    hipError_t he = hipEventSynchronize(e1);
-    if (he == hipSuccess) he = hipEventElapsedTime(ms_out, e0, e1);
-    if (he != hipSuccess) rc = dia_fail_hip(he, "dia_mlp_fused_timed");
-  }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  return rc;
+  float ms[2] = {0.f, 0.f};
+  const int n = dia_recorder_collect(ms, 2);
+  if (rc != DIA_OK) return rc;
+  if (n < 1) return n < 0 ? n : dia_fail(DIA_E_STATE, "dia_mlp_fused_timed: nothing was launched");
+  *ms_out = ms[0];
+  return DIA_OK;
 }

@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
+#include "launch.hpp"
 
 namespace {
 
@@ -257,7 +258,7 @@ extern "C" int dia_dec_prefill_embed(const dia_dec_prefill_args* a, void* stream
   PrefK k; int rc = fill(a, k); if (rc) return rc;
   if (!a->tokens || !a->emb || !a->x || !a->P || !a->ssq || a->C <= 0 || a->C > 16 || a->D % 16 != 0 || a->p_ktiles * 32 < a->D || a->p_plane_stride % 8 != 0)
     return dia_fail(DIA_E_ARG, "dia_dec_prefill_embed: bad argument");
-  hipLaunchKernelGGL(k_prefill_embed, dim3(a->rows), dim3(256), 0, (hipStream_t)stream, k);
+  dia_launch<k_prefill_embed>(dim3(a->rows), dim3(256), 0, (hipStream_t)stream, k);
   return dia_check_launch("k_prefill_embed");
 }
 
@@ -265,7 +266,7 @@ extern "C" int dia_dec_prefill_kv(const dia_dec_prefill_args* a, void* stream) {
   PrefK k; int rc = fill(a, k); if (rc) return rc;
   if (!a->q || !a->kc || !a->vc || !a->cos_t || !a->sin_t || a->kv_heads <= 0 || a->kv_cap % 32 != 0)
     return dia_fail(DIA_E_ARG, "dia_dec_prefill_kv: bad argument");
-  hipLaunchKernelGGL(k_prefill_kv, dim3(a->kv_heads, a->rows / 32), dim3(256), 0, (hipStream_t)stream, k);
+  dia_launch<k_prefill_kv>(dim3(a->kv_heads, a->rows / 32), dim3(256), 0, (hipStream_t)stream, k);
   return dia_check_launch("k_prefill_kv");
 }
 
@@ -274,6 +275,6 @@ extern "C" int dia_dec_prefill_attn(const dia_dec_prefill_args* a, void* stream)
   if (!a->q || !a->kc || !a->vc || !a->cos_t || !a->sin_t || !a->P || a->q_heads <= 0 || a->kv_heads <= 0 || a->q_heads % a->kv_heads != 0 ||
       a->kv_cap % 32 != 0 || (!a->causal && !a->text_len) || a->p_plane_stride % 8 != 0 || (a->q_heads * 128 + 31) / 32 > a->p_ktiles)
     return dia_fail(DIA_E_ARG, "dia_dec_prefill_attn: bad argument");
-  hipLaunchKernelGGL(k_prefill_attn, dim3(a->q_heads, a->rows / 16), dim3(256), 0, (hipStream_t)stream, k);
+  dia_launch<k_prefill_attn>(dim3(a->q_heads, a->rows / 16), dim3(256), 0, (hipStream_t)stream, k);
   return dia_check_launch("k_prefill_attn");
 }

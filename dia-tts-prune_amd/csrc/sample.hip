@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "../../include/dia_hip.h"
 #include "errors.hpp"
+#include "launch.hpp"
 
 namespace {
 
@@ -378,7 +379,7 @@ extern "C" int dia_embed_tokens(const dia_embed_args* a, void* stream) {
   EmbedK e;
   int rc = fill_embed(a, e);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_embed_tokens, dim3(a->B), dim3(256), 0, (hipStream_t)stream, e);
+  dia_launch<k_embed_tokens>(dim3(a->B), dim3(256), 0, (hipStream_t)stream, e);
   return dia_check_launch("k_embed_tokens");
 }
 
@@ -387,7 +388,7 @@ extern "C" int dia_embed_text(const int32_t* ids, int L, const float* table, int
                               void* stream) {
   if (!ids || !table || !x || !P || !ssq || L <= 0 || D % 16 != 0 || (!cmap && p_ktiles * 32 < D) || p_plane_stride % 8 != 0)
     return dia_fail(DIA_E_ARG, "dia_embed_text: bad argument");
-  hipLaunchKernelGGL(k_embed_text, dim3(L), dim3(256), 0, (hipStream_t)stream, ids, L, table, D, g, x,
+  dia_launch<k_embed_text>(dim3(L), dim3(256), 0, (hipStream_t)stream, ids, L, table, D, g, x,
                      (bf16_raw*)P, (long)p_plane_stride, p_ktiles, ssq, ssq_ld, cmap);
   return dia_check_launch("k_embed_text");
 }
@@ -425,6 +426,6 @@ extern "C" int dia_sample(const dia_sample_args* a, void* stream) {
     rc = dia_kernels_init_once();
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_sample, dim3(a->B), dim3(a->C * 64), smem, (hipStream_t)stream, k);
+  dia_launch<k_sample>(dim3(a->B), dim3(a->C * 64), smem, (hipStream_t)stream, k);
   return dia_check_launch("k_sample");
 }

@@ -22,7 +22,7 @@ ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
 EXPORTS = (
     "dia_last_error", "dia_abi_version", "dia_device_count", "dia_set_tuning", "dia_get_tuning", "dia_has_experiments", "dia_gemm", "dia_gemm_timed", "dia_mlp_fused", "dia_mlp_fused_timed", "dia_engine_mlp_fused", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep", "dia_enc_attn", "dia_dec_prefill_embed", "dia_dec_prefill_kv", "dia_dec_prefill_attn",
     "dia_embed_text", "dia_embed_tokens", "dia_sample", "dia_prefetch", "dia_engine_create", "dia_engine_destroy",
-    "dia_engine_decode", "dia_engine_set_prefetch", "dia_engine_step_logits_only", "dia_engine_profile_step", "dia_engine_launches_per_step",
+    "dia_engine_decode", "dia_engine_set_prefetch", "dia_engine_step_logits_only", "dia_engine_profile_step", "dia_engine_time_step", "dia_timed_kernel_name", "dia_engine_launches_per_step",
 )
 
 
@@ -194,6 +194,9 @@ def lib() -> C.CDLL:
     L.dia_engine_set_prefetch.argtypes = [C.c_void_p, C.c_int]
     L.dia_engine_launches_per_step.argtypes = [C.c_void_p]
     L.dia_engine_profile_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    L.dia_engine_time_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    L.dia_timed_kernel_name.argtypes = [C.c_int]
+    L.dia_timed_kernel_name.restype = C.c_char_p
     _lib = L
     return L
 

@@ -174,6 +174,40 @@ class DeviceWeights:
         npos = max(cfg.data.audio_length, cfg.data.text_length) + 1
         cos, sin = lay.rope_tables(npos, HEAD_DIM, m.rope_min_timescale, m.rope_max_timescale)
         self.cos_t, self.sin_t = cos.to(device), sin.to(device)
+        self.flat = None
+        self.pack_flat()
+
+    def tensors(self) -> List[torch.Tensor]:
+        """Every device tensor of the model, in a deterministic order (the layout of the flat arena)."""
+        out: List[torch.Tensor] = [self.enc_emb]
+        for L in self.enc_layers:
+            out += [L["g_sa"], L["g_mlp"], L["qkv"].t, L["o"].t, L["wi"].t, L["wo"].t]
+            out += [L[k] for k in ("cmap_mlp", "cmap_next") if L[k] is not None]
+        out += [self.enc_norm, self.dec_emb]
+        for L in self.dec_layers:
+            out += [L["g_sa"], L["g_ca"], L["g_mlp"]] + [L[k].t for k in ("qkv", "o", "cq", "co", "ckv", "wi", "wo")]
+            out += [L[k] for k in ("cmap_ca", "cmap_mlp", "cmap_next", "smap_qkv", "smap_cq", "smap_ckv", "hmap_self", "hmap_cross")
+                    if L[k] is not None]
+        out += [self.dec_norm, self.logits.t, self.cos_t, self.sin_t]
+        out += [t for t in (self.cmap_first, self.enc_cmap_first) if t is not None]
+        return out
+
+    def pack_flat(self):
+        """Move every tensor into ONE contiguous byte arena (256-byte aligned slots, order of tensors()): the model is a
+        single HBM allocation, and the multi-GPU weight distribution is a single broadcast of it (one
+        ncclBroadcast of the repacked weights).  Tensor objects keep their identity; only their storage moves."""
+        ts = self.tensors()
+        offs, tot = [], 0
+        for t in ts:
+            offs.append(tot)
+            tot += (t.numel() * t.element_size() + 255) // 256 * 256
+        flat = torch.zeros(tot, dtype=torch.uint8, device=self.device)
+        for t, o in zip(ts, offs):
+            nb = t.numel() * t.element_size()
+            v = flat[o: o + nb].view(t.dtype).view(t.shape)
+            v.copy_(t)
+            t.data = v
+        self.flat = flat
 
     @classmethod
     def empty_like_config(cls, cfg: DiaConfig, device: torch.device) -> "DeviceWeights":
@@ -681,6 +715,19 @@ class DecodeSession:
         hb.check(hb.lib().dia_engine_profile_step(self._engine, buf, n), "dia_engine_profile_step")
         self._issued += 1
         return np.array(buf[:], dtype=np.float64)
+
+    def time_step(self) -> np.ndarray:
+        """kernel durations (milliseconds, launch order) of one eager decode step, each kernel bracketed by its own
+        dispatch-level start / stop events — what rocprofv3 --kernel-trace reports per kernel."""
+        n = hb.lib().dia_engine_launches_per_step(self._engine)
+        buf = (C.c_float * n)()
+        self.ensure_noise(self._issued + 1)
+        got = hb.lib().dia_engine_time_step(self._engine, buf, n)
+        if got < 0:
+            hb.check(got, "dia_engine_time_step")
+        self._issued += 1
+        self.last_kernel_names = [hb.lib().dia_timed_kernel_name(i).decode() for i in range(got)]
+        return np.array(buf[:got], dtype=np.float64)
 
     def time_wi_launches(self, reps: int = 5) -> float:
         """Average seconds per launch of the dominant kernel — the wi_fused GEMV with SwiGLU epilogue —

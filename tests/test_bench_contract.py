@@ -35,3 +35,13 @@ def test_other_config_lines():
         d = _line(name)
         assert d["config"]["batch_per_gpu"] == 8 and d["value"] > 0 and d["roofline"]["traffic"] is None
         assert d.get("cpu_baseline") is None             # the CPU leg runs in the default (batch 1, N = 1) invocation only
+
+
+def test_default_batch_follows_baseline_configs():
+    """N = 1: BASELINE configs[1] (batch 1); N > 1: configs[4], 64 utterances over the N GPUs"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.default_batch(1) == 1
+    assert [bench.default_batch(n) for n in (2, 4, 8)] == [32, 16, 8]
+    assert bench.MIXED_L == [32, 64, 96, 128, 192, 256, 384, 512] and sum(bench.MIXED_L) == 1664

@@ -73,8 +73,92 @@ def test_weight_tensor_inventory_is_complete():
         elif hasattr(o, "t") and isinstance(getattr(o, "t"), torch.Tensor):
             seen.add(id(o.t))
 
-    for v in vars(w).values():
-        walk(v)
+    for name, v in vars(w).items():
+        if name != "flat":
+            walk(v)
     assert seen == ids
+    # every tensor lives inside the one flat arena (a single allocation = a single broadcast)
+    lo, hi = w.flat.data_ptr(), w.flat.data_ptr() + w.flat.numel()
+    for t in D.weight_tensors(w):
+        assert lo <= t.data_ptr() and t.data_ptr() + t.numel() * t.element_size() <= hi
+        assert t.data_ptr() % 256 == lo % 256
     z = DeviceWeights.empty_like_config(cfg, torch.device("cpu"))
     assert [tuple(t.shape) for t in D.weight_tensors(z)] == [tuple(t.shape) for t in D.weight_tensors(w)]
+    assert z.flat.numel() == w.flat.numel()
+
+
+def _worker_model(rank, world, port, q):
+    """rank 0 holds the model, the other ranks receive it in ONE broadcast of the flat arena; then 5 utterances are
+    sharded u -> u mod world, every rank decodes its own (the CPU oracle on the tiny config stands in for the HIP session)
+    and the token buffers are gathered back in utterance order."""
+    sys.path.insert(0, os.path.join(ROOT, "dia-tts-prune_amd"))
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from dia_hip import config as C
+    from dia_hip import dist as D
+    from dia_hip.engine import DeviceWeights
+    from dia_hip.weights import synthetic_state_dict
+    from oracle import dia_oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = C.mid_config()                 # real head_dim (the device layouts are built for 128)
+    sd = synthetic_state_dict(cfg, seed=7, std=0.02)
+    cpu = torch.device("cpu")
+    w = DeviceWeights(cfg, sd, cpu) if rank == 0 else DeviceWeights.empty_like_config(cfg, cpu)
+    calls = []
+    orig = dist.broadcast
+
+    def counting(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+
+    dist.broadcast = counting
+    nbytes = D.broadcast_weights(w, src=0)
+    dist.broadcast = orig
+    ref = DeviceWeights(cfg, sd, cpu)
+    same = all(torch.equal(a, b) for a, b in zip(D.weight_tensors(w), D.weight_tensors(ref)))
+    texts = ["[S1] one.", "[S2] two two.", "[S1] three three three.", "[S1] four. [S2] four.", "[S2] five!"]
+    mt = 10
+    mine = D.shard_utterances(len(texts), world, rank)
+    local = [torch.from_numpy(O.generate(sd, cfg, texts[u], max_tokens=mt, seed=100 + u, keep_logits=False).tokens) for u in mine]
+    allb = D.gather_utterances(local, len(texts), world, rank)
+    q.put((rank, same, len(calls), nbytes == w.flat.numel(), mine, [b.numpy() for b in allb]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_one_broadcast_and_sharded_decode():
+    sys.path.insert(0, os.path.join(ROOT, "dia-tts-prune_amd"))
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from dia_hip import config as C
+    from dia_hip.weights import synthetic_state_dict
+    from oracle import dia_oracle as O
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker_model, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(2)), key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, ncalls, nb_ok, mine, bufs in res:
+        assert same and nb_ok
+        assert ncalls == 1                                   # the whole model travels in ONE collective
+        assert mine == [u for u in range(5) if u % 2 == rank]
+    # single-process run of all five utterances: the gathered buffers are those, in utterance order, on both ranks
+    cfg = C.mid_config()
+    sd = synthetic_state_dict(cfg, seed=7, std=0.02)
+    texts = ["[S1] one.", "[S2] two two.", "[S1] three three three.", "[S1] four. [S2] four.", "[S2] five!"]
+    torch.set_num_threads(4)
+    for u, t in enumerate(texts):
+        want = O.generate(sd, cfg, t, max_tokens=10, seed=100 + u, keep_logits=False).tokens
+        for _, _, _, _, _, bufs in res:
+            assert np.array_equal(bufs[u], want), u

@@ -25,14 +25,18 @@ def test_bench_two_ranks_share_device():
     env = dict(os.environ, DIA_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "32", "--warmup", "4",
-           "--cpu-steps", "0", "--profile-steps", "0"]
+           "--cpu-steps", "0", "--profile-steps", "0", "--batch", "3"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    if r.returncode != 0:                                      # the children's own tracebacks come before the launcher's summary
+        i = r.stderr.find("Traceback")
+        raise AssertionError(f"bench.py --gpus 2 failed (rc {r.returncode}):\n" + (r.stderr[i: i + 3000] if i >= 0 else r.stderr[-3000:]))
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 alone prints
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 32 and d["warmup"] == 4 and d["scaling"] == "weak"
-    assert d["config"]["parallelism"] == "dp2" and d["config"]["batch_per_gpu"] == 1
-    assert d["value"] > 0 and abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) <= 1e-2 * d["value"]     # whole-job frames/s
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["batch_per_gpu"] == 3
+    assert "6 utterances sharded data-parallel over 2 GPUs" in d["config"]["workload"]
+    assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 1000.0 / d["ms_per_step"]) <= 1e-2 * d["value"]     # whole-job frames/s
+    assert "configs" not in d                                 # the single-GPU configuration sweep belongs to N = 1
     assert d["weights_bcast_s"] > 0
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None
