@@ -76,41 +76,48 @@ def launch_bytes(sess, w, n_keys: int):
     return out
 
 
-def kernel_table(sess, w, reps: int):
-    """Per kernel instantiation: launches per step, mean duration (dispatch-level begin/end timestamps of `reps` eager
-    steps chained behind a device-side delay = what rocprofv3 --kernel-trace reports), mean algorithmic bytes, GB/s."""
+def kernel_table(sess, w, reps: int, graph_step_us: float):
+    """Per kernel instantiation, live: `reps` eager steps chained behind a device-side delay, every kernel bracketed by its own
+    dispatch-level start / stop events (timestamps of the dispatch packet).
+      kernel_us      mean begin -> end of the kernel itself
+      us_per_launch  kernel_us + boundary, boundary = (graph-replayed step time - sum of kernel_us) / launches: what a launch
+                     costs inside the replayed chain.  rocprofv3 --kernel-trace reports this quantity as the kernel's
+                     duration under graph replay (its begin[n+1] == end[n]: the durations partition the step), so the
+                     committed profiles/*kernel_stats* averages are the cross-check; the roofline fractions use it.
+    The eager chain itself is NOT the measure of step time (per-kernel events add ~5 us between launches)."""
     names, ms = None, []
     for _ in range(reps):
-        t = sess.time_step()
+        ms.append(sess.time_step())
         names = sess.last_kernel_names
-        ms.append(t)
     ms = np.stack(ms)                                   # [reps, launches]
     n_keys = int(sess.cur.max().item())
     byts = launch_bytes(sess, w, n_keys)
     nl = sess.cfg.model.decoder.n_layer
     ops = [LAUNCH_NAMES[i % 8] for i in range(nl * 8)] + ["logits", "sample_fsm_embed"]
-    step_us = float(ms.sum(axis=1).mean() * 1e3)
+    kus = ms.mean(axis=0) * 1e3                          # per launch
+    boundary = max(0.0, (graph_step_us - float(kus.sum())) / len(kus))
     tab = {}
     for i, nm in enumerate(names):
-        e = tab.setdefault(nm, {"launches_per_step": 0, "us": 0.0, "bytes": 0.0, "ops": set()})
+        e = tab.setdefault(nm, {"launches_per_step": 0, "kus": 0.0, "bytes": 0.0, "ops": set()})
         e["launches_per_step"] += 1
-        e["us"] += float(ms[:, i].mean() * 1e3)
+        e["kus"] += float(kus[i])
         e["bytes"] += byts[i] if i < len(byts) else 0
         e["ops"].add(ops[i] if i < len(ops) else "?")
     rows = []
     for nm, e in tab.items():
         n = e["launches_per_step"]
-        us, b = e["us"] / n, e["bytes"] / n
+        k_us, b = e["kus"] / n, e["bytes"] / n
+        us = k_us + boundary
         rows.append({"kernel": nm, "ops": sorted(e["ops"]), "launches_per_step": n, "us_per_launch": round(us, 3),
-                     "bytes_per_launch": int(b), "achieved": round(b / (us * 1e-6) / 1e9, 1) if us > 0 else 0.0,
-                     "frac": round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else 0.0,
-                     "share_of_kernel_time": round(e["us"] / step_us, 4)})
-    rows.sort(key=lambda r: -r["share_of_kernel_time"])
+                     "kernel_us": round(k_us, 3), "bytes_per_launch": int(b),
+                     "achieved": round(b / (us * 1e-6) / 1e9, 1), "frac": round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "share_of_step_time": round(us * n / graph_step_us, 4)})
+    rows.sort(key=lambda r: -r["share_of_step_time"])
     per_op = {}
-    for i, o in enumerate(ops[: ms.shape[1]]):
-        per_op.setdefault(o, []).append(float(ms[:, i].mean() * 1e3))
+    for i, o in enumerate(ops[: len(kus)]):
+        per_op.setdefault(o, []).append(float(kus[i]) + boundary)
     per_op = {o: round(float(np.mean(v)), 3) for o, v in per_op.items()}
-    return rows, per_op, step_us
+    return rows, per_op, round(boundary, 3)
 
 
 def measure(w, cfg, *, batch, kv, steps, warmup, use_graph=True, seeds=None, dist=None, dev=None, profile_reps=0):
@@ -185,10 +192,10 @@ def measure(w, cfg, *, batch, kv, steps, warmup, use_graph=True, seeds=None, dis
                              "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
            "prefill": prefill}
     if profile_reps > 0:
-        rows, per_op, step_us = kernel_table(sess, w, profile_reps)
+        rows, per_op, boundary = kernel_table(sess, w, profile_reps, dev_ms / steps * 1e3)
         out["kernels"] = rows
         out["us_per_launch_by_op"] = per_op
-        out["kernel_time_per_step_us"] = round(step_us, 1)
+        out["boundary_us_per_launch"] = boundary
     sess.close()
     return out
 
@@ -306,13 +313,16 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "ops": top["ops"], "launches_per_step": top["launches_per_step"],
                            "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"],
                            "bytes_per_launch": top["bytes_per_launch"], "us_per_launch": top["us_per_launch"],
-                           "share_of_kernel_time": top["share_of_kernel_time"], "traffic": traffic, "traffic_source": src,
-                           "how": "dominant kernel BY TIME of the decode step; us = mean begin->end timestamp of the dispatch packet over "
-                                  f"{args.profile_steps} eager steps chained behind a device-side delay (the duration rocprofv3 "
-                                  "--kernel-trace reports); bytes = mean algorithmic bytes of its launches (SURVEY.md §8d)"}
+                           "kernel_us": top["kernel_us"], "share_of_step_time": top["share_of_step_time"], "traffic": traffic,
+                           "traffic_source": src,
+                           "how": "dominant kernel BY TIME of the decode step.  kernel_us = mean begin -> end of its dispatches (HIP start/stop "
+                                  f"events per kernel, {args.profile_steps} eager steps on the engine's stream); us_per_launch = kernel_us + "
+                                  "boundary_us_per_launch = (graph-replayed step time - sum of kernel_us) / launches: its cost inside the replayed "
+                                  "chain, the quantity rocprofv3 --kernel-trace reports as its duration there (begin[n+1] == end[n]); achieved = "
+                                  "mean algorithmic bytes of its launches (SURVEY.md §8d) / us_per_launch"}
         out["roofline_by_kernel"] = rows
         out["us_per_launch_by_op"] = m["us_per_launch_by_op"]
-        out["kernel_time_per_step_us"] = m["kernel_time_per_step_us"]
+        out["boundary_us_per_launch"] = m["boundary_us_per_launch"]
 
     # ---- the other single-GPU configurations of BASELINE.json, 1024 steps each whatever --steps says
     if rank == 0 and world == 1 and not args.no_configs and not args.pruned and args.batch in (0, 1) and args.kv == "bf16":

@@ -328,14 +328,14 @@ extern "C" int dia_engine_profile_step(dia_engine* e, float* ms, int cap) {
 
 // One eager step behind the same device-side delay, every kernel bracketed by its own dispatch-level start / stop
 // events (launch.hpp): ms[i] = duration of the i-th kernel of the step, in launch order, as rocprofv3 would report it.
-extern "C" int dia_engine_time_step(dia_engine* e, float* ms, int cap) {
+extern "C" int dia_engine_time_step(dia_engine* e, float* ms, float* interval_ms, int cap) {
   if (!e || !ms) return dia_fail(DIA_E_ARG, "dia_engine_time_step: null argument");
   const int n = e->d.n_layer * 8 + 2;
   if (cap < n) return dia_fail(DIA_E_ARG, "dia_engine_time_step: output array too small");
   dia_launch<k_delay>(dim3(1), dim3(64), 0, e->stream, 300000LL /* 100 MHz ticks = 3 ms */);
   dia_recorder_arm();
   int rc = enqueue_step(e, true);
-  const int got = dia_recorder_collect(ms, cap);
+  const int got = dia_recorder_collect(ms, cap, interval_ms);
   hipError_t he = hipStreamSynchronize(e->stream);
   if (rc != DIA_OK) return rc;
   if (he != hipSuccess) return dia_fail_hip(he, "dia_engine_time_step: hipStreamSynchronize");

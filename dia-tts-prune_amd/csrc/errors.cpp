@@ -52,7 +52,7 @@ const char* dia_recorder_label(int i) {
   return (i >= 0 && i < (int)g_last_labels.size()) ? g_last_labels[i].c_str() : "";
 }
 
-int dia_recorder_collect(float* out_ms, int cap) {
+int dia_recorder_collect(float* out_ms, int cap, float* out_interval_ms) {
   dia_launch_recorder& r = dia_recorder();
   r.armed = false;
   int rc = (int)r.ev.size();
@@ -65,7 +65,16 @@ int dia_recorder_collect(float* out_ms, int cap) {
       float ms = -1.f;
       if (hipEventElapsedTime(&ms, r.ev[i].first, r.ev[i].second) != hipSuccess) { ms = -1.f; (void)hipGetLastError(); }
       out_ms[i] = ms;
+      // end of the previous kernel -> end of this one: what a launch costs inside a dependent chain, boundary included
+      // (rocprofv3 reports exactly this as the "duration" of a kernel in a replayed graph: begin[n+1] == end[n] there)
+      if (out_interval_ms) {
+        float iv = ms;
+        if (i > 0 && hipEventElapsedTime(&iv, r.ev[i - 1].second, r.ev[i].second) != hipSuccess) { iv = -1.f; (void)hipGetLastError(); }
+        out_interval_ms[i] = iv;
+      }
     }
+  }
+  for (size_t i = 0; i < r.ev.size(); ++i) {
     (void)hipEventDestroy(r.ev[i].first); (void)hipEventDestroy(r.ev[i].second);
   }
   r.ev.clear();

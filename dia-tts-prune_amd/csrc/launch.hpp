@@ -15,10 +15,10 @@ struct dia_launch_recorder {
 };
 dia_launch_recorder& dia_recorder();          // thread-local
 // arm: subsequent launches of this thread are recorded.  collect: synchronises on the last stop event, writes the
-// kernel durations (ms, launch order) into out[0..cap), returns their count (or a negative DIA_E_*), disarms and
-// releases the events.
+// kernel durations (ms, launch order) into out[0..cap) and, when asked, the end-to-end intervals between consecutive
+// kernels, returns their count (or a negative DIA_E_*), disarms and releases the events.
 void dia_recorder_arm();
-int dia_recorder_collect(float* out_ms, int cap);
+int dia_recorder_collect(float* out_ms, int cap, float* out_interval_ms = nullptr);
 // kernel instantiation name of the i-th launch of the last collected recording ("k_gemv_small<8, 8, 2, false>"), or ""
 const char* dia_recorder_label(int i);
 

@@ -194,7 +194,7 @@ def lib() -> C.CDLL:
     L.dia_engine_set_prefetch.argtypes = [C.c_void_p, C.c_int]
     L.dia_engine_launches_per_step.argtypes = [C.c_void_p]
     L.dia_engine_profile_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
-    L.dia_engine_time_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    L.dia_engine_time_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
     L.dia_timed_kernel_name.argtypes = [C.c_int]
     L.dia_timed_kernel_name.restype = C.c_char_p
     _lib = L

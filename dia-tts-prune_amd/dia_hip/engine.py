@@ -720,13 +720,14 @@ class DecodeSession:
         """kernel durations (milliseconds, launch order) of one eager decode step, each kernel bracketed by its own
         dispatch-level start / stop events — what rocprofv3 --kernel-trace reports per kernel."""
         n = hb.lib().dia_engine_launches_per_step(self._engine)
-        buf = (C.c_float * n)()
+        buf, ivl = (C.c_float * n)(), (C.c_float * n)()
         self.ensure_noise(self._issued + 1)
-        got = hb.lib().dia_engine_time_step(self._engine, buf, n)
+        got = hb.lib().dia_engine_time_step(self._engine, buf, ivl, n)
         if got < 0:
             hb.check(got, "dia_engine_time_step")
         self._issued += 1
         self.last_kernel_names = [hb.lib().dia_timed_kernel_name(i).decode() for i in range(got)]
+        self.last_intervals_ms = np.array(ivl[:got], dtype=np.float64)      # end of launch i-1 -> end of launch i
         return np.array(buf[:got], dtype=np.float64)
 
     def time_wi_launches(self, reps: int = 5) -> float:

@@ -379,10 +379,12 @@ int dia_engine_step_logits_only(dia_engine* e);
  * return the elapsed milliseconds of each launch (launch order: per layer qkv, attn_self, o, cq,
  * attn_cross, co, wi, wo; then logits, sampler).  Synchronises the stream. */
 int dia_engine_profile_step(dia_engine* e, float* ms_per_launch, int cap);
-/* run ONE eager decode step with every kernel bracketed by dispatch-level start / stop events (the kernel's own begin /
- * end timestamps, the quantity rocprofv3 --kernel-trace reports): ms_per_kernel[i] = duration of the i-th launch, same
- * order as dia_engine_profile_step.  Returns the number of kernels launched or a negative DIA_E_*.  Synchronises. */
-int dia_engine_time_step(dia_engine* e, float* ms_per_kernel, int cap);
+/* run ONE eager decode step with every kernel bracketed by dispatch-level start / stop events (timestamps of the
+ * dispatch packet itself): ms_per_kernel[i] = begin -> end of the i-th launch (pure execution), interval_ms[i] (may be
+ * NULL) = end of launch i-1 -> end of launch i = what the launch costs inside the dependent chain, boundary included —
+ * the quantity rocprofv3 --kernel-trace reports as a kernel's duration in a replayed graph (begin[i] == end[i-1] there).
+ * Same order as dia_engine_profile_step.  Returns the number of kernels launched or a negative DIA_E_*.  Synchronises. */
+int dia_engine_time_step(dia_engine* e, float* ms_per_kernel, float* interval_ms, int cap);
 /* kernel instantiation name (as rocprofv3 prints it, without the namespace) of the i-th launch of the calling thread's
  * last dia_engine_time_step / dia_gemm_timed; "" when out of range */
 const char* dia_timed_kernel_name(int i);
