@@ -159,12 +159,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
   bf16x8 b0[KPW], b1[MULTI ? KPW : 1];
   constexpr int KT = NW * KPW;             // the dispatcher only picks this kernel when p.KT == NW*KPW
   constexpr int NT = NW * 64;
-
-  const int e_r = (tid >> 1) & 15, half = tid & 1;
-  const int m = e_r;
-  const bool e_thread = tid < 32;
-  const bool live = e_thread && m < p.M;
-  float xpre[8], gpre[8];
+#ifdef DIA_X_WFIRST
+  load_strip(b0, blockIdx.x);                       // the HBM stream starts here
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 
   // ---- every small, L2-resident operand is requested BEFORE the weight stream, branch-free: vmcnt
   // retires in order, so anything queued behind 16-32 KiB of HBM loads per wave would stall its first
@@ -193,8 +191,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
   }
   // (3) residual row + next norm weight of the first strip (RESID_EMIT only)
   const bool resid = p.epi == DIA_EPI_RESID_EMIT;
-  const bool rows_epi = resid || p.epi == DIA_EPI_SWIGLU_EMIT;      // one element per thread (run_epilogue_rows)
-  const bool r_thread = tid < 16 * RS;
+  const bool r_thread = tid < 16 * RS;                // one tile element per thread in the epilogue (run_epilogue_rows)
   float xpre1 = 0.f, gpre1 = 1.f;
   auto load_resid = [&](int strip) {
     const int r_m = tid >> 4, n = strip * 16 + (tid & 15);
@@ -203,8 +200,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
   };
   if (resid && r_thread) load_resid(blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
+#ifndef DIA_X_WFIRST
   load_strip(b0, blockIdx.x);                       // the HBM stream starts here
   __builtin_amdgcn_sched_barrier(0);
+#endif
   STAMP(1);
 #pragma unroll
   for (int u = 0; u < CH; ++u)
@@ -215,15 +214,23 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
     for (int i = 0; i < 16; ++i) s0 += (s_part + 8 * i < p.ssq_in_n && s_row < p.M) ? sq[i] : 0.f;
     if (s_thread && s_row < p.M)
       for (int idx = s_part + 128; idx < p.ssq_in_n; idx += 8) s0 += p.ssq_in[(long)idx * p.ssq_ld + s_row];   // D > 2048 only
-    s0 += __shfl_xor(s0, 1, 64);
-    s0 += __shfl_xor(s0, 2, 64);
-    s0 += __shfl_xor(s0, 4, 64);
+    // the 8 partials of a row sit in 8 consecutive lanes: quad xor 1, quad xor 2, then the other quad of the half row
+    // (after two steps a quad is uniform, so the mirror delivers what lane ^ 4 holds) — DPP, no LDS crossbar
+    s0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+    s0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));
+    s0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x141, 0xF, 0xF, true));
     if (tid < 128 && s_part == 0) inv_s[s_row] = has_norm ? rsqrtf(s0 * p.inv_d + p.eps) : 1.0f;
   }
   lds_barrier();      // A image + row scales visible; the weight loads stay in flight
   STAMP(2);
 
   const int arow = min(lane & 15, RS - 1), akq = lane >> 4;
+  // cross-wave sum of the partial tiles.  Only rows 0..3 of the 16x16 tile can be valid (M <= 4): they live in lanes 0..15
+  // (registers = rows), so a wave hands over 256 bytes, and thread (row m, column c) of the epilogue adds the NW
+  // partials of ITS element in wave order — one barrier, no tile round trip (the old form wrote all 64 lanes, summed on
+  // one wave, wrote a tile and met at a second barrier).  Double-buffered across the strips of the persistent form.
+  f32x4* red16 = red;                                 // [2][NW][16]
+  int sbuf = 0;
   auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
     const int next = strip + G;
     if constexpr (MULTI) { if (next < p.nstrips) load_strip(bn, next); }     // next strip's weights stream while this one computes
@@ -237,17 +244,28 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
       }
     }
     STAMP(3);
-    reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
-    STAMP(4);
-    if (!MULTI) { if (!splitk_combine(p, tile, strip, tid, &sk_flag)) return; }
-    if (rows_epi) {
+    float v = 0.f;
+    if (MULTI || gridDim.y == 1) {
+      f32x4* rb = red16 + sbuf * (NW * 16);
+      sbuf ^= 1;
+      if (lane < 16) rb[w * 16 + lane] = acc[0];
+      lds_barrier();
       if (r_thread) {
-        run_epilogue_rows<RS>(p, tile, inv_s, tid, strip, xpre1, gpre1);
-        if (MULTI && next < p.nstrips && resid) load_resid(next);      // residual operands of the next strip
+        const float* rf = reinterpret_cast<const float*>(rb) + (tid & 15) * 4 + (tid >> 4);
+        v = rf[0];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) v += rf[ww * 64];
       }
-    } else if (e_thread) {
-      const int n0 = strip * 16 + half * 8;
-      run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
+      STAMP(4);
+    } else {              // cross-workgroup split-K (wo): partial tile -> slab, the last arriver sums the slabs in split order
+      reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
+      STAMP(4);
+      if (!splitk_combine(p, tile, strip, tid, &sk_flag)) return;
+      if (r_thread) v = tile[(tid >> 4) * 17 + (tid & 15)];
+    }
+    if (r_thread) {
+      run_epilogue_rows<RS>(p, v, inv_s, tid, strip, xpre1, gpre1);
+      if (MULTI && next < p.nstrips && resid) load_resid(next);      // residual operands of the next strip
     }
   };
   if constexpr (MULTI) {

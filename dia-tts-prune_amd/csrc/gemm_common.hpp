@@ -171,30 +171,33 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
   }
 }
 
-// M <= RS rows (k_gemv_small): RESID_EMIT and SWIGLU_EMIT with ONE element per thread (16*RS threads: row = tid / 16,
-// column = tid % 16) instead of eight per thread on half a wave — the 32-thread form spends 0.5 us of single-wave issue time
-// (8 three-way bf16 splits per thread) at the very end of every o / co / wo / wi launch.  Results are bit-identical
-// to run_epilogue: the strip's sum of squares is accumulated in the same order (columns 0..7 of each half in
-// sequence, rounded squares and plain adds, then half 0 + half 1) through lane shifts.
+// DPP moves inside rows of 16 lanes (no LDS crossbar, a few cycles): lane i takes lane i - n / i + n of its row
+#define DIA_ROW_SHR(v, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x110 + (n), 0xF, 0xF, true))
+#define DIA_ROW_SHL(v, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x100 + (n), 0xF, 0xF, true))
+
+// M <= RS rows (k_gemv_small): every decode epilogue with ONE element per thread (16*RS threads: row = tid / 16, column =
+// tid % 16; `v` = that element of the finished 16x16 tile) instead of eight per thread on half a wave — the 32-thread form
+// spends 0.5 us of single-wave issue time (8 three-way bf16 splits per thread) at the very end of every launch.  Results are
+// bit-identical to run_epilogue: the strip's sum of squares is accumulated in the same order (columns 0..7 of each half in
+// sequence, rounded squares and plain adds, then half 0 + half 1), carried from lane to lane by DPP row shifts.
 template <int RS>
-__device__ __forceinline__ void run_epilogue_rows(const GemmK& p, const float* tile, const float* inv_s, int tid, int strip,
+__device__ __forceinline__ void run_epilogue_rows(const GemmK& p, float v_tile, const float* inv_s, int tid, int strip,
                                                   float xpre1, float gpre1) {
   const int m = tid >> 4, c = tid & 15;
   const bool live = m < p.M;
   if (p.epi == DIA_EPI_RESID_EMIT) {
     const int n = strip * 16 + c;
-    const float v = xpre1 + tile[m * 17 + c];
+    const float v = xpre1 + v_tile;
     if (live) p.out[(long)m * p.ldo + n] = v;
     const float sq = mul_rn(v, v);      // (the 32-thread form squares with packed multiplies and adds in sequence: no FMA)
     float acc = sq;
 #pragma unroll
     for (int j = 1; j < 8; ++j) {
-      const float t = __shfl_up(acc, 1, 64);
+      const float t = DIA_ROW_SHR(acc, 1);
       if ((c & 7) == j) acc = add_rn(t, sq);
     }
-    const int lane = tid & 63;
-    const float h0 = __shfl(acc, (lane & ~15) | 7, 64), h1 = __shfl(acc, (lane & ~15) | 15, 64);
-    if (live && c == 0) p.ssq_out[(long)strip * p.ssq_ld + m] = h0 + h1;
+    const float h0 = DIA_ROW_SHR(acc, 8);                               // lane 15 of the row: the sum of columns 0..7
+    if (live && c == 15) p.ssq_out[(long)strip * p.ssq_ld + m] = h0 + acc;
     const float vg = mul_rn(v, gpre1);
     int cc = n;
     if (p.cmap) cc = p.cmap[n];
@@ -206,10 +209,11 @@ __device__ __forceinline__ void run_epilogue_rows(const GemmK& p, const float* t
       p.P[p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&b);
       p.P[2 * p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&d);
     }
-  } else {  // DIA_EPI_SWIGLU_EMIT: columns 0..7 gate, 8..15 up
+  } else if (p.epi == DIA_EPI_SWIGLU_EMIT) {    // columns 0..7 gate, 8..15 up
+    const float up_raw = DIA_ROW_SHL(v_tile, 8);                        // lane c < 8 takes column c + 8
     if (!live || c >= 8) return;
     const float inv = inv_s[m];
-    const float g = tile[m * 17 + c] * inv, u = tile[m * 17 + 8 + c] * inv;
+    const float g = v_tile * inv, u = up_raw * inv;
     const float v = (g / (1.0f + expf(-g))) * u;
     __bf16 a, b, d;
     split3(v, a, b, d);
@@ -217,6 +221,10 @@ __device__ __forceinline__ void run_epilogue_rows(const GemmK& p, const float* t
     p.P[off] = *reinterpret_cast<bf16_raw*>(&a);
     p.P[p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&b);
     p.P[2 * p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&d);
+  } else {                                      // DIA_EPI_SCALE_STORE
+    if (!live) return;
+    const int s_out = p.strip_map ? p.strip_map[strip] : strip;         // compacted output: whole heads dropped
+    p.out[(long)m * p.ldo + s_out * 16 + c] = v_tile * inv_s[m];
   }
 }
 
