@@ -92,8 +92,10 @@ __device__ __forceinline__ void attn_finish(const AttnK& p, const float* part, c
     float* slab = p.scratch + (pair * p.max_chunks + chunk) * SLAB;
     if (o_thread) {
       if ((tid & 15) == 0) st2_agent(slab + 2 * og, M, Lsum);
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) st2_agent(slab + 16 + og * HD + od0 + j, o[j], o[j + 1]);
+      const __amdgpu_buffer_rsrc_t sr = agent_rsrc(p.scratch);
+      const int so = (int)(((pair * p.max_chunks + chunk) * SLAB + 16 + og * HD + od0) * 4);
+      st4_agent(sr, so, f32x4{o[0], o[1], o[2], o[3]});
+      st4_agent(sr, so + 16, f32x4{o[4], o[5], o[6], o[7]});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -107,43 +109,44 @@ __device__ __forceinline__ void attn_finish(const AttnK& p, const float* part, c
     ASTAMP(5);
     if (!last_s) return;
     if (o_thread) {
+      // the last arriver merges the slabs in chunk order (deterministic).  Only the LIVE slabs are read, MB per round
+      // trip, every load of a round issued before the first is waited for: (m, l) as one 8-byte and the 8 output dims
+      // as two 16-byte coherent loads per slab (72 eight-byte loads per lane for 24 slabs, live or not, took 2.8 us of
+      // an 8.5 us launch at batch 1)
       const float* base = p.scratch + pair * p.max_chunks * SLAB;
-      constexpr int MAXC = 24;               // 3072 keys / 128
-      float mc[MAXC], lcs[MAXC];
-#pragma unroll
-      for (int c = 0; c < MAXC; ++c) {       // independent loads
-        const float2 ml = ld2_agent(base + (long)min(c, nchunks - 1) * SLAB + 2 * og);
-        mc[c] = ml.x; lcs[c] = ml.y;
-      }
+      const __amdgpu_buffer_rsrc_t sr = agent_rsrc(p.scratch);
+      const int bo = (int)((pair * p.max_chunks * SLAB + 16 + og * HD + od0) * 4);
       constexpr int MB = 12;                 // slabs per round trip
-      float mm = -INFINITY;
-      float L2 = 0.f;
+      float mrun = -INFINITY, L2 = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = 0.f;
-      for (int c0 = 0; c0 < nchunks; c0 += MB) {                    // chunk order: deterministic
-        float2 ov[MB][4];
+      for (int c0 = 0; c0 < nchunks; c0 += MB) {
+        float2 ml[MB]; f32x4 oa[MB], ob[MB];
 #pragma unroll
-        for (int u = 0; u < MB; ++u) {
-          const float* sl = base + (long)min(c0 + u, nchunks - 1) * SLAB + 16 + og * HD + od0;
+        for (int u = 0; u < MB; ++u)
+          if (c0 + u < nchunks) {            // (uniform over the workgroup)
+            const float* sl = base + (long)(c0 + u) * SLAB;
+            ml[u] = ld2_agent(sl + 2 * og);
+            oa[u] = ld4_agent(sr, bo + (c0 + u) * (SLAB * 4));
+            ob[u] = ld4_agent(sr, bo + (c0 + u) * (SLAB * 4) + 16);
+          }
+        float mm = mrun;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) ov[u][j] = ld2_agent(sl + 2 * j);
-        }
-        if (c0 == 0) {
+        for (int u = 0; u < MB; ++u)
+          if (c0 + u < nchunks) mm = fmaxf(mm, ml[u].x);
+        const float fr = (mrun == -INFINITY) ? 0.f : expf(mrun - mm);      // earlier rounds (capacity > 1536 keys only)
+        L2 *= fr;
 #pragma unroll
-          for (int c = 0; c < MAXC; ++c) mm = fmaxf(mm, mc[c]);
-          for (int c = MAXC; c < nchunks; ++c) mm = fmaxf(mm, ld2_agent(base + (long)c * SLAB + 2 * og).x);   // capacity > 3072 only
-        }
+        for (int j = 0; j < 8; ++j) o[j] *= fr;
 #pragma unroll
-        for (int u = 0; u < MB; ++u) {
-          const int c = c0 + u;
-          float mcu, lcu;
-          if (c0 == 0) { mcu = mc[u]; lcu = lcs[u]; }               // (u < MB <= MAXC)
-          else { const float2 ml = ld2_agent(base + (long)min(c, nchunks - 1) * SLAB + 2 * og); mcu = ml.x; lcu = ml.y; }
-          const float f = (c < nchunks && mcu != -INFINITY) ? expf(mcu - mm) : 0.f;
-          L2 += lcu * f;
+        for (int u = 0; u < MB; ++u)
+          if (c0 + u < nchunks) {
+            const float f = (ml[u].x != -INFINITY) ? expf(ml[u].x - mm) : 0.f;
+            L2 += ml[u].y * f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { o[2 * j] += ov[u][j].x * f; o[2 * j + 1] += ov[u][j].y * f; }
-        }
+            for (int j = 0; j < 4; ++j) { o[j] += oa[u][j] * f; o[4 + j] += ob[u][j] * f; }
+          }
+        mrun = mm;
       }
       Lsum = L2;
     }

@@ -81,6 +81,22 @@ __device__ __forceinline__ float2 ld2_agent(const float* p) {
   return float2{__uint_as_float((unsigned)(v & 0xffffffffull)), __uint_as_float((unsigned)(v >> 32))};
 }
 
+// 16-byte device-coherent accesses: buffer_load / buffer_store_dwordx4 sc1 through the raw-buffer builtins (cache policy
+// bit 4 = sc1 on gfx94x/gfx950), which the compiler tracks like any other load — there is no 128-bit atomic to lower to,
+// and hand-written global_load asm is invisible to its wait-count insertion.  One 16-byte access replaces two 8-byte
+// ones: the write-through / coherent-read paths handle 8-byte requests at 0.5-0.7x the 16-byte rate per byte.
+// `base` must be wave-uniform (a kernel argument); offsets are bytes below 2 GiB.
+typedef unsigned int dia_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t agent_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld4_agent(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+__device__ __forceinline__ void st4_agent(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dia_u32x4, v), r, byte_off, 0, 16);
+}
+
 // compacted consumers: column n0+j goes to plane position cmap[n0+j] (2-byte stores), or nowhere
 __device__ __forceinline__ void emit_planes8_mapped(bf16_raw* P, long plane_stride, int ktiles, int m, int n0,
                                                     const float* v, const int* cmap) {

@@ -18,7 +18,7 @@ def report(tag, nwg):
         if len(c): print(f"   {n:20s} n {len(c):5d} min {(c.min()-t0)/100:6.2f}  median {(np.median(c)-t0)/100:6.2f}  max {(c.max()-t0)/100:6.2f} us")
 def clear():
     pass
-for B, cur, T in ((1, 1040, 3072), (8, 1040, 3072), (8, 300, 3072), (8, 2500, 3072)):
+for B, cur, T in ((1, 1040, 3072), (1, 300, 3072), (8, 1040, 3072), (8, 300, 3072)):
     R, QH, KVH = 2 * B, 16, 4
     nq = (QH + 2 * KVH) * 128
     qkv = torch.randn(R, nq, device=d)
@@ -40,8 +40,7 @@ for B, cur, T in ((1, 1040, 3072), (8, 1040, 3072), (8, 300, 3072), (8, 2500, 30
     for _ in range(3):
         hb.check(L.dia_attn(C.byref(a), None), "attn")
     torch.cuda.synchronize()
-    big.fill_(1)          # push K/V out of L2 / MALL like the weight stream does in a real step
-    torch.cuda.synchronize()
     L.dia_dbg_aclear()
-    hb.check(L.dia_attn(C.byref(a), None), "attn"); torch.cuda.synchronize()
+    big.fill_(1)          # push K/V out of L2 / MALL like the weight stream does in a real step; NO sync after it: the
+    hb.check(L.dia_attn(C.byref(a), None), "attn"); torch.cuda.synchronize()      # stamped launch starts in-chain (an isolated launch starts its XCDs up to 1.4 us apart)
     report(f"self B={B} cur={cur} T={T} nz={nz}", KVH * R * nz)
