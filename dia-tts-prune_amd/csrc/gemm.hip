@@ -294,8 +294,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   p.A = a_A; p.a_plane_stride = a_aps; p.W = a_W; p.KT = a_KT; p.M = a_M; p.epi = a_epi; p.nstrips = a_nstrips;
   p.out = a_out; p.ldo = a_ldo; p.gnext = a_gnext;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [NW][64]
-  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * NW * 64);   // [16][17]
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                         // [2][NW][64]
+  bf16_raw* stg = reinterpret_cast<bf16_raw*>(smem_raw + sizeof(f32x4) * 2 * NW * 64);   // [3][16][16] plane staging
+  float* tile = reinterpret_cast<float*>(smem_raw + sizeof(f32x4) * 2 * NW * 64 + 1536);   // [16][17]
   float* inv_s = tile + 16 * 17;                                           // [16]
   constexpr int NT = NW * 64;
 
@@ -326,11 +327,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   };
   bf16x8 b0[KPW], b1[MULTI ? KPW : 1];
 
-  const int e_r = (tid >> 1) & 15, half = tid & 1;
-  const int m = e_r;
-  const bool e_thread = tid < 32;
-  const bool live = e_thread && m < p.M;
-  float xpre[8], gpre[8];
+  // epilogue geometry: thread t < 256 owns element (row t / 16, column t % 16) of the finished 16 x 16 tile
+  const int r16 = tid >> 4, c16 = tid & 15;
+  const bool r_thread = tid < 256;
+  float xpre1 = 0.f, gpre1 = 1.f;
 
   // A fragments (rows >= M alias the last valid row: no extra L2 traffic, results never stored)
   const int alane = (lane & 48) | min(lane & 15, p.M - 1);
@@ -354,16 +354,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   }
   const bool resid = p.epi == DIA_EPI_RESID_EMIT;
   auto load_resid = [&](int strip) {
-    const int n0 = strip * 16 + half * 8;
-    const float* o = p.out + (long)(live ? m : 0) * p.ldo + n0;
-    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
-    xpre[0] = xa.x; xpre[1] = xa.y; xpre[2] = xa.z; xpre[3] = xa.w;
-    xpre[4] = xb.x; xpre[5] = xb.y; xpre[6] = xb.z; xpre[7] = xb.w;
-    const float4 ga = *reinterpret_cast<const float4*>(p.gnext + n0), gb = *reinterpret_cast<const float4*>(p.gnext + n0 + 4);
-    gpre[0] = ga.x; gpre[1] = ga.y; gpre[2] = ga.z; gpre[3] = ga.w;
-    gpre[4] = gb.x; gpre[5] = gb.y; gpre[6] = gb.z; gpre[7] = gb.w;
+    const int n = strip * 16 + c16;
+    xpre1 = p.out[(long)(r16 < p.M ? r16 : 0) * p.ldo + n];
+    gpre1 = p.gnext[n];
   };
-  if (resid && e_thread) load_resid(blockIdx.x);
+  if (resid && r_thread) load_resid(blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
   load_strip(b0, blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
@@ -373,12 +368,18 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
     for (int i = 0; i < 16; ++i) s0 += (s_part + 8 * i < p.ssq_in_n && s_row < p.M) ? sq[i] : 0.f;
     if (s_thread && s_row < p.M)
       for (int idx = s_part + 128; idx < p.ssq_in_n; idx += 8) s0 += p.ssq_in[(long)idx * p.ssq_ld + s_row];
-    s0 += __shfl_xor(s0, 1, 64);
-    s0 += __shfl_xor(s0, 2, 64);
-    s0 += __shfl_xor(s0, 4, 64);
+    s0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));    // see k_gemv_small
+    s0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));
+    s0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x141, 0xF, 0xF, true));
     if (tid < 128 && s_part == 0) inv_s[s_row] = has_norm ? rsqrtf(s0 * p.inv_d + p.eps) : 1.0f;
   }
 
+  // Cross-wave sum + epilogue, one tile element per thread (256 threads): the NW partial tiles go to LDS whole, a thread adds
+  // the partials of ITS element in wave order (one barrier, double-buffered over the strips of the persistent form)
+  // and runs the epilogue arithmetic for it — the three-way bf16 split of 256 elements spread over four waves instead
+  // of eight per thread on half a wave.  The planes still leave as 16-byte stores: the bf16 triples are staged in LDS
+  // (1.5 KB) and 96 threads store a row half of a plane each (768 two-byte stores per tile were measured slower).
+  int sbuf = 0;
   auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
     const int next = strip + G;
     if constexpr (MULTI) { if (next < p.nstrips) load_strip(bn, next); }
@@ -388,15 +389,99 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
 #pragma unroll
       for (int pl = 0; pl < DIA_NPLANES; ++pl)
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], bc[i], acc[0], 0, 0, 0);
-    reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
-    const bool last_slice = splitk_combine(p, tile, strip, tid, &sk_flag);      // workgroup-uniform; true without split-K
-    // (one element per thread as in k_gemv_small was measured here too: bit-identical, 1.3 % SLOWER at batch 8 - 768
-    // two-byte plane stores per tile instead of 96 sixteen-byte ones)
-    if (e_thread) {
-      const int n0 = strip * 16 + half * 8;
-      if (last_slice) run_epilogue(p, tile + e_r * 17, inv_s[e_r], m, n0, half, strip, live, xpre, gpre);
-      if (MULTI && next < p.nstrips && resid) load_resid(next);
+    float v = 0.f;
+    bool last_slice = true;
+    if (gridDim.y == 1) {
+      f32x4* rb = red + sbuf * (NW * 64);
+      sbuf ^= 1;
+      rb[w * 64 + lane] = acc[0];
+      lds_barrier();
+      if (r_thread) {
+        const float* rf = reinterpret_cast<const float*>(rb) + (c16 + 16 * (r16 >> 2)) * 4 + (r16 & 3);
+        v = rf[0];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) v += rf[ww * 256];
+      }
+    } else {
+      reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
+      last_slice = splitk_combine(p, tile, strip, tid, &sk_flag);      // workgroup-uniform
+      if (last_slice && r_thread) v = tile[r16 * 17 + c16];
     }
+    if (last_slice) {
+      const bool live = r_thread && r16 < p.M;
+      if (p.epi == DIA_EPI_SCALE_STORE) {
+        if (live) {
+          const int s_out = p.strip_map ? p.strip_map[strip] : strip;
+          p.out[(long)r16 * p.ldo + s_out * 16 + c16] = v * inv_s[r16];
+        }
+      } else {
+        float e = 0.f;                              // the value whose planes are emitted
+        int ecol = c16;                             // its column inside the emitted row segment
+        bool emit = false;
+        if (resid) {
+          if (r_thread) {
+            const int n = strip * 16 + c16;
+            const float xv = xpre1 + v;
+            if (live) p.out[(long)r16 * p.ldo + n] = xv;
+            const float sqv = mul_rn(xv, xv);
+            float accs = sqv;
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+              const float t = DIA_ROW_SHR(accs, 1);
+              if ((c16 & 7) == j) accs = add_rn(t, sqv);
+            }
+            const float h0 = DIA_ROW_SHR(accs, 8);
+            if (live && c16 == 15) p.ssq_out[(long)strip * p.ssq_ld + r16] = h0 + accs;
+            e = mul_rn(xv, gpre1);
+            emit = live;
+          }
+        } else {                                    // SWIGLU: columns 0..7 gate, 8..15 up
+          if (r_thread) {
+            const float up_raw = DIA_ROW_SHL(v, 8);
+            const float inv = inv_s[r16];
+            const float g = v * inv, u = up_raw * inv;
+            e = (g / (1.0f + expf(-g))) * u;
+            emit = live && c16 < 8;
+          }
+        }
+        __bf16 ea, eb, ec;
+        split3(e, ea, eb, ec);
+        if (resid && p.cmap) {                      // compacted consumer: scattered two-byte stores
+          if (emit) {
+            const int cc = p.cmap[strip * 16 + c16];
+            if (cc >= 0) {
+              const long off = plane_frag_off(r16, cc & ~7, p.p_ktiles) + (cc & 7);
+              p.P[off] = *reinterpret_cast<bf16_raw*>(&ea);
+              p.P[p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&eb);
+              p.P[2 * p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&ec);
+            }
+          }
+        } else {
+          if (r_thread) {
+            stg[(0 * 16 + r16) * 16 + ecol] = *reinterpret_cast<bf16_raw*>(&ea);
+            stg[(1 * 16 + r16) * 16 + ecol] = *reinterpret_cast<bf16_raw*>(&eb);
+            stg[(2 * 16 + r16) * 16 + ecol] = *reinterpret_cast<bf16_raw*>(&ec);
+          }
+          lds_barrier();
+          if (resid) {
+            if (tid < 96) {
+              const int pl = tid >> 5, mm = (tid & 31) >> 1, hh = tid & 1;
+              if (mm < p.M) {
+                const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&stg[(pl * 16 + mm) * 16 + hh * 8]);
+                *reinterpret_cast<bf16x8*>(p.P + pl * p.p_plane_stride + plane_frag_off(mm, strip * 16 + hh * 8, p.p_ktiles)) = t8;
+              }
+            }
+          } else if (tid < 48) {
+            const int pl = tid >> 4, mm = tid & 15;
+            if (mm < p.M) {
+              const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&stg[(pl * 16 + mm) * 16]);
+              *reinterpret_cast<bf16x8*>(p.P + pl * p.p_plane_stride + plane_frag_off(mm, strip * 8, p.p_ktiles)) = t8;
+            }
+          }
+        }
+      }
+    }
+    if (MULTI && next < p.nstrips && resid && r_thread) load_resid(next);
   };
   if constexpr (MULTI) {
     for (int strip = blockIdx.x; strip < p.nstrips; strip += 2 * G) {
@@ -600,7 +685,7 @@ int launch_tile(const GemmK& k, hipStream_t st) {
 
 template <int NW, int KPW>
 int launch_g16(const GemmK& k, hipStream_t st) {
-  const size_t smem = sizeof(f32x4) * NW * 64 + sizeof(float) * (16 * 17 + 16);
+  const size_t smem = sizeof(f32x4) * 2 * NW * 64 + 1536 + sizeof(float) * (16 * 17 + 16);
   const int sk = k.KT / (NW * KPW);
   int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
   const int mz = k.mz > 1 ? k.mz : 1;

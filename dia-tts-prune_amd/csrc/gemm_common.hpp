@@ -259,10 +259,12 @@ __device__ __forceinline__ bool splitk_combine(const GemmK& p, float* tile, int 
   const int ks = blockIdx.y;
   // hand-off through device-coherent (sc1) accesses with explicit ordering, no cache-wide fences — see
   // attn_finish in attn.hip
-  float* slab = p.sk_scratch + ((long)strip * SK + ks) * 256;
-  if (tid < 128) {
-    const int e = tid * 2;
-    st2_agent(slab + e, tile[(e >> 4) * 17 + (e & 15)], tile[(e >> 4) * 17 + (e & 15) + 1]);
+  // 16-byte coherent accesses: 64 threads carry the 16 x 16 tile (one row quarter each)
+  const __amdgpu_buffer_rsrc_t sr = agent_rsrc(p.sk_scratch);
+  const int row = tid >> 2, c4 = (tid & 3) * 4;                   // tid < 64
+  if (tid < 64) {
+    const float* t = tile + row * 17 + c4;
+    st4_agent(sr, (int)((((long)strip * SK + ks) * 256 + row * 16 + c4) * 4), f32x4{t[0], t[1], t[2], t[3]});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -274,12 +276,21 @@ __device__ __forceinline__ bool splitk_combine(const GemmK& p, float* tile, int 
   }
   __syncthreads();
   if (!*flag_s) return false;
-  if (tid < 128) {
-    const int e = tid * 2;
-    const float* base = p.sk_scratch + (long)strip * SK * 256 + e;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < SK; ++k) { const float2 v = ld2_agent(base + k * 256); a += v.x; b += v.y; }
-    tile[(e >> 4) * 17 + (e & 15)] = a; tile[(e >> 4) * 17 + (e & 15) + 1] = b;
+  if (tid < 64) {
+    f32x4 v[4];                                                   // SK <= 4: every slab requested before the first is used
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < SK) v[k] = ld4_agent(sr, (int)((((long)strip * SK + k) * 256 + row * 16 + c4) * 4));
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < SK) { a[0] += v[k][0]; a[1] += v[k][1]; a[2] += v[k][2]; a[3] += v[k][3]; }
+    for (int k = 4; k < SK; ++k) {
+      const f32x4 t = ld4_agent(sr, (int)((((long)strip * SK + k) * 256 + row * 16 + c4) * 4));
+      a[0] += t[0]; a[1] += t[1]; a[2] += t[2]; a[3] += t[3];
+    }
+    float* t = tile + row * 17 + c4;
+    t[0] = a[0]; t[1] = a[1]; t[2] = a[2]; t[3] = a[3];
   }
   __syncthreads();
   return true;
