@@ -146,7 +146,16 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     // per strip, which also brings the per-wave K range down to what k_gemm16 keeps in registers (23.2 ->
     // 18.4 us in the step at batch 8).  Shapes without a split kernel fall back to one workgroup per strip.
     int wo_sk = (R <= 4 && L.kt_wo % 2 == 0) ? 2 : ((R <= 16 && L.kt_wo % 4 == 0) ? 4 : 1);
-    if (dia_tune(DIA_TUNE_WO_SK) >= 1 && dia_tune(DIA_TUNE_WO_SK) <= 4) wo_sk = dia_tune(DIA_TUNE_WO_SK);
+    int wo_spw = 0;
+    if (R > 4 && R <= 16) {
+      // 5..16 rows: K ranges of 64 k-tiles (8 waves x 8 k-tiles keep their A fragments in registers: 160 VGPRs, one
+      // workgroup per CU) and as many strips per workgroup as it takes to stay at one round of <= 256 workgroups —
+      // dense wo (K 8192 x 128 strips): 4 ranges x 64 strip PAIRS, both tiles of a pair handed over together
+      // (14.3 -> 11.7 us); the 50 %-pruned wo (K 4096): 2 ranges x 128 strips
+      if (L.kt_wo % 64 == 0 && L.kt_wo / 64 >= 2 && L.kt_wo / 64 <= 8) wo_sk = L.kt_wo / 64;
+      if (wo_sk > 1 && L.ns_wo * wo_sk >= 512 && L.ns_wo % 2 == 0) wo_spw = 2;
+    }
+    if (dia_tune(DIA_TUNE_WO_SK) >= 1 && dia_tune(DIA_TUNE_WO_SK) <= 8 && L.kt_wo % dia_tune(DIA_TUNE_WO_SK) == 0) wo_sk = dia_tune(DIA_TUNE_WO_SK);
     g.sk = wo_sk; g.sk_scratch = wo_sk > 1 ? d.sk_scratch : nullptr; g.sk_tickets = wo_sk > 1 ? d.sk_tickets : nullptr;
     bool wo_pair = false;
     if (R > 16 && R <= 128) {     // 2..8 m-tiles: split-K 4 over every m-tile (k_gemm16 with gridDim.z) when the scratch covers
@@ -157,6 +166,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
       g.sk = wo_pair ? 4 : 1;
     }
     if (dia_tune(DIA_TUNE_WO_NW) > 0) g.nw = dia_tune(DIA_TUNE_WO_NW);
+    g.spw = wo_spw;
     if (dia_tune(DIA_TUNE_WO_SPW) > 0) g.spw = dia_tune(DIA_TUNE_WO_SPW);
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D;
     g.gnext = (l + 1 < d.n_layer) ? e->layers[l + 1].g_sa : d.g_final;

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
     for (int i = 0; i < KPW; ++i) b[i] = (MZ && ZTEMPORAL) ? *(Wt + (long)i * 64) : DIA_WLOAD(Wt + (long)i * 64);   // z-form: the other m-tiles re-read these lines from L2
   };
   bf16x8 b0[KPW], b1[MULTI ? KPW : 1];
+  STAMP(0);
 
   // epilogue geometry: thread t < 256 owns element (row t / 16, column t % 16) of the finished 16 x 16 tile
   const int r16 = tid >> 4, c16 = tid & 15;
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   __builtin_amdgcn_sched_barrier(0);
   load_strip(b0, blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
   {
     float s0 = 0.f;
 #pragma unroll
@@ -379,35 +381,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   // and runs the epilogue arithmetic for it — the three-way bf16 split of 256 elements spread over four waves instead
   // of eight per thread on half a wave.  The planes still leave as 16-byte stores: the bf16 triples are staged in LDS
   // (1.5 KB) and 96 threads store a row half of a plane each (768 two-byte stores per tile were measured slower).
-  int sbuf = 0;
-  auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
-    const int next = strip + G;
-    if constexpr (MULTI) { if (next < p.nstrips) load_strip(bn, next); }
-    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int i = 0; i < KPW; ++i)
-#pragma unroll
-      for (int pl = 0; pl < DIA_NPLANES; ++pl)
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], bc[i], acc[0], 0, 0, 0);
-    float v = 0.f;
-    bool last_slice = true;
-    if (gridDim.y == 1) {
-      f32x4* rb = red + sbuf * (NW * 64);
-      sbuf ^= 1;
-      rb[w * 64 + lane] = acc[0];
-      lds_barrier();
-      if (r_thread) {
-        const float* rf = reinterpret_cast<const float*>(rb) + (c16 + 16 * (r16 >> 2)) * 4 + (r16 & 3);
-        v = rf[0];
-#pragma unroll
-        for (int ww = 1; ww < NW; ++ww) v += rf[ww * 256];
-      }
-    } else {
-      reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
-      last_slice = splitk_combine(p, tile, strip, tid, &sk_flag);      // workgroup-uniform
-      if (last_slice && r_thread) v = tile[r16 * 17 + c16];
-    }
-    if (last_slice) {
+  // epilogue of one finished tile: thread t < 256 holds element (t / 16, t % 16) in `v`; xp / gp = its residual and norm weight
+  auto finish = [&](int strip, float v, float xpre1, float gpre1) {
+    {
       const bool live = r_thread && r16 < p.M;
       if (p.epi == DIA_EPI_SCALE_STORE) {
         if (live) {
@@ -481,7 +457,120 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
         }
       }
     }
+  };
+  // Split-K with exactly two strips per workgroup (wo at 5..16 rows: 64 strip pairs x 4 K ranges = 256 workgroups, one per
+  // CU, one round): both tiles are computed first and handed over TOGETHER — one slab publication, one ticket, one merge
+  // by the last arriver — instead of one dependent hand-off chain per strip.  (512 one-strip workgroups at 160 VGPRs run
+  // in two rounds, one workgroup per CU: 14.3 us; a hand-off per strip inside the persistent loop: 14.5 us.)
+  if constexpr (MULTI) {
+    if (gridDim.y > 1 && 2 * G == p.nstrips) {
+      const int s0 = blockIdx.x, s1 = blockIdx.x + G;
+      float xpreB = 0.f, gpreB = 1.f;
+      if (resid && r_thread) { const float xa = xpre1, ga = gpre1; load_resid(s1); xpreB = xpre1; gpreB = gpre1; xpre1 = xa; gpre1 = ga; }
+      load_strip(b1, s1);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KPW; ++i)
+#pragma unroll
+        for (int pl = 0; pl < DIA_NPLANES; ++pl) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], b0[i], acc0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < KPW; ++i)
+#pragma unroll
+        for (int pl = 0; pl < DIA_NPLANES; ++pl) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], b1[i], acc1, 0, 0, 0);
+      STAMP(2);
+      red[w * 64 + lane] = acc0;
+      red[NW * 64 + w * 64 + lane] = acc1;
+      lds_barrier();
+      float v0 = 0.f, v1 = 0.f;
+      if (r_thread) {
+        const float* rf = reinterpret_cast<const float*>(red) + (c16 + 16 * (r16 >> 2)) * 4 + (r16 & 3);
+        v0 = rf[0]; v1 = rf[NW * 256];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) { v0 += rf[ww * 256]; v1 += rf[NW * 256 + ww * 256]; }
+      }
+      STAMP(3);
+      // publish both partial tiles (element-per-thread, 4-byte coherent stores would be slow: go through LDS rows)
+      const int SK = gridDim.y, ks = blockIdx.y;
+      float* tile1 = tile + 16 * 17 + 16;               // second tile behind tile + inv_s
+      if (r_thread) { tile[r16 * 17 + c16] = v0; tile1[r16 * 17 + c16] = v1; }
+      lds_barrier();
+      const __amdgpu_buffer_rsrc_t sr = agent_rsrc(p.sk_scratch);
+      if (tid < 128) {
+        const int tsel = tid >> 6, row = (tid & 63) >> 2, c4 = (tid & 3) * 4;
+        const float* t = (tsel ? tile1 : tile) + row * 17 + c4;
+        st4_agent(sr, (int)((((long)(tsel ? s1 : s0) * SK + ks) * 256 + row * 16 + c4) * 4), f32x4{t[0], t[1], t[2], t[3]});
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(p.sk_tickets + s0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == SK - 1;
+        if (last) __hip_atomic_store(p.sk_tickets + s0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sk_flag = last;
+      }
+      __syncthreads();
+      STAMP(4);
+      if (!sk_flag) return;
+      if (tid < 128) {
+        const int tsel = tid >> 6, row = (tid & 63) >> 2, c4 = (tid & 3) * 4;
+        const long sb = (long)(tsel ? s1 : s0) * SK;
+        f32x4 q[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          if (kk < SK) q[kk] = ld4_agent(sr, (int)(((sb + kk) * 256 + row * 16 + c4) * 4));
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          if (kk < SK) { sum[0] += q[kk][0]; sum[1] += q[kk][1]; sum[2] += q[kk][2]; sum[3] += q[kk][3]; }
+        for (int kk = 4; kk < SK; ++kk) {
+          const f32x4 t = ld4_agent(sr, (int)(((sb + kk) * 256 + row * 16 + c4) * 4));
+          sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
+        }
+        float* t = (tsel ? tile1 : tile) + row * 17 + c4;
+        t[0] = sum[0]; t[1] = sum[1]; t[2] = sum[2]; t[3] = sum[3];
+      }
+      lds_barrier();
+      if (r_thread) { v0 = tile[r16 * 17 + c16]; v1 = tile1[r16 * 17 + c16]; }
+      finish(s0, v0, xpre1, gpre1);
+      finish(s1, v1, xpreB, gpreB);
+      STAMP(5);
+      return;
+    }
+  }
+  int sbuf = 0;
+  auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
+    const int next = strip + G;
+    if constexpr (MULTI) { if (next < p.nstrips) load_strip(bn, next); }
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl)
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], bc[i], acc[0], 0, 0, 0);
+    STAMP(2);
+    float v = 0.f;
+    bool last_slice = true;
+    if (gridDim.y == 1) {
+      f32x4* rb = red + sbuf * (NW * 64);
+      sbuf ^= 1;
+      rb[w * 64 + lane] = acc[0];
+      lds_barrier();
+      if (r_thread) {
+        const float* rf = reinterpret_cast<const float*>(rb) + (c16 + 16 * (r16 >> 2)) * 4 + (r16 & 3);
+        v = rf[0];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) v += rf[ww * 256];
+      }
+    } else {
+      reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
+      STAMP(3);
+      last_slice = splitk_combine(p, tile, strip, tid, &sk_flag);      // workgroup-uniform
+      STAMP(4);
+      if (last_slice && r_thread) v = tile[r16 * 17 + c16];
+    }
+    if (last_slice) finish(strip, v, xpre1, gpre1);
     if (MULTI && next < p.nstrips && resid && r_thread) load_resid(next);
+    STAMP(5);
   };
   if constexpr (MULTI) {
     for (int strip = blockIdx.x; strip < p.nstrips; strip += 2 * G) {
@@ -685,7 +774,7 @@ int launch_tile(const GemmK& k, hipStream_t st) {
 
 template <int NW, int KPW>
 int launch_g16(const GemmK& k, hipStream_t st) {
-  const size_t smem = sizeof(f32x4) * 2 * NW * 64 + 1536 + sizeof(float) * (16 * 17 + 16);
+  const size_t smem = sizeof(f32x4) * 2 * NW * 64 + 1536 + sizeof(float) * (2 * 16 * 17 + 16);
   const int sk = k.KT / (NW * KPW);
   int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
   const int mz = k.mz > 1 ? k.mz : 1;
@@ -785,9 +874,12 @@ int launch_small(const GemmK& k, hipStream_t st) {
   // strips per workgroup: enough workgroups to cover every CU, few enough that each streams several
   // strips back to back (next strip's loads overlap this strip's reduce + epilogue)
   int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
+  const int sk = k.KT / (NW * KPW);          // cross-workgroup split-K factor (1 = none)
+  // between one and two rounds of resident workgroups (logits head: 579 strips, two 8-wave workgroups per CU): walk the
+  // strips with about 256 persistent workgroups instead of leaving a short second round
+  if (k.spw <= 0 && sk == 1 && k.nstrips > 512 && k.nstrips < 1024) spw = (k.nstrips + 255) / 256;
   if (dia_tune(DIA_TUNE_GEMM_SPW) > 0) spw = dia_tune(DIA_TUNE_GEMM_SPW);
   const int grid = (k.nstrips + spw - 1) / spw;
-  const int sk = k.KT / (NW * KPW);          // cross-workgroup split-K factor (1 = none)
   if (sk > 1) {
     launch_small_kernel<k_gemv_small<NW, KPW, RS, false>>(dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
     return dia_check_launch("k_gemv_small");

@@ -298,7 +298,7 @@ __device__ __forceinline__ bool splitk_combine(const GemmK& p, float* tile, int 
 
 #ifdef DIA_DBG_STAMPS
 __device__ long long g_stamps[4096 * 8];
-#define STAMP(i) do { if (tid == 0) g_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define STAMP(i) do { if (tid == 0) g_stamps[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif

@@ -764,3 +764,37 @@ def test_attn_self_head_map(kvd, B, cur):
             worst = max(worst, (out[r, int(hmap[h])] - ref[0]).abs().max().item())
     assert worst <= 2e-5, worst
     assert (out[:R, nl:] == sentinel).all() and (out[R:] == sentinel).all()      # head positions >= live count: not written
+
+
+@pytest.mark.parametrize("M,K,D,sk", [(16, 8192, 2048, 4), (9, 4096, 2048, 2), (16, 4096, 512, 4), (32, 8192, 2048, 4)])
+def test_gemm_split_k_paired_strips(M, K, D, sk):
+    """split-K with two strips per workgroup (spw = 2): both tiles handed over in ONE slab publication / ticket / merge.
+    Bit-identical to the one-strip-per-workgroup split-K (same partial tiles, same slab order), twice, tickets re-armed."""
+    d = dev()
+    torch.manual_seed(K + D + M)
+    a = torch.randn(M, K, device=d)
+    W = bf16r(torch.randn(K, D, device=d) * 0.03)
+    x0 = torch.randn(M, D, device=d)
+    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+    Wt, kt, ns = lay.tile_weight(W)
+    mpad = (M + 15) // 16 * 16
+    mt = mpad // 16
+    outs = []
+    for spw in (1, 2, 2):
+        x = x0.clone()
+        P = torch.zeros(3, mt, D // 32, 64, 8, dtype=torch.bfloat16, device=d)
+        ssq = torch.zeros(ns, mpad, device=d)
+        g, A = _gemm_args(a, Wt, kt, ns, hb.EPI_RESID_EMIT)
+        g.ssq_ld, g.out, g.ldo, g.gnext = mpad, hb.ptr(x), D, hb.ptr(gn)
+        g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), D // 32, hb.ptr(ssq)
+        scr = torch.zeros(mt * ns * sk * 256, device=d)
+        tk = torch.zeros(mt * ns, dtype=torch.int32, device=d)
+        g.sk_scratch, g.sk_tickets, g.sk, g.sk_scratch_floats, g.spw = hb.ptr(scr), hb.ptr(tk), sk, scr.numel(), spw
+        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+        torch.cuda.synchronize()
+        assert (tk == 0).all()
+        outs.append((x, P.clone(), ssq))
+    ref = x0.double() + a.double() @ W.double()
+    assert (outs[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
