@@ -220,6 +220,90 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
         for (int i = 0; i < NV; ++i) if (key[i] < pre) lg[i] = -INFINITY;
       }
       SSTAMP(2);
+      // ---- survivors of the top-k cut.  With at most 64 of them (k = 35 plus ties: the usual case) everything that
+      // follows — softmax, top-p ordering, final softmax, multinomial — runs on ONE element per lane instead of 17
+      // registers of mostly -inf.  The arithmetic is the general path's, bit for bit: the softmax denominators are
+      // accumulated per ORIGINAL lane in index order and then summed by the same butterfly (lanep[] below).
+      int nsv = 0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) nsv += __popcll(__ballot(lg[i] != -INFINITY));
+      if (nsv >= 1 && nsv <= 64) {
+        float* lanep = lp + 128;                       // [64] per-original-lane partial sums
+        float* srt = lp + 256;                         // [64] probabilities in sorted order
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {                 // compaction in increasing vocabulary index (index = 64 i + lane)
+          const unsigned long long mk = __ballot(lg[i] != -INFINITY);
+          if (lg[i] != -INFINITY) {
+            const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
+            lp[pos] = lg[i]; sp[pos] = qn[i]; li[pos] = (unsigned short)(lane + 64 * i);
+          }
+          base += __popcll(mk);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool act = lane < nsv;
+        const float l = act ? lp[lane] : -INFINITY;
+        const float q1 = act ? sp[lane] : 1.0f;
+        const int idx = act ? (int)li[lane] : 0x7fff;
+        const int Lc = idx & 63;
+        // occurrence number of this element among the survivors of its original lane (increasing index)
+        int occ = 0;
+        for (int j = 0; j < nsv; ++j) {
+          const int lj = __builtin_amdgcn_readlane(Lc, j);
+          occ += (j < lane && lj == Lc) ? 1 : 0;
+        }
+        int maxocc = occ;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxocc = max(maxocc, __shfl_xor(maxocc, o, 64));
+        auto lane_order_sum = [&](float e) {           // sum over all elements exactly as the 17-register form does it
+          lanep[lane] = 0.f;
+          __builtin_amdgcn_wave_barrier();
+          for (int r = 0; r <= maxocc; ++r) {
+            if (act && occ == r) lanep[Lc] = lanep[Lc] + e;
+            __builtin_amdgcn_wave_barrier();
+          }
+          const float zl = lanep[lane];
+          __builtin_amdgcn_wave_barrier();
+          return wave_sum(zl);
+        };
+        float lcur = l;
+        if (p.top_p < 1.0f) {                          // model.py:56-70
+          const float m = wave_max(l);
+          const float e = act ? expf(l - m) : 0.f;
+          const float z = lane_order_sum(e);
+          const float pr = e / z;
+          const bool actp = act && pr > 0.f;           // (a survivor whose probability underflows sorts after everything)
+          const int ns = __popcll(__ballot(actp));
+          int r = 0;
+          for (int j = 0; j < nsv; ++j) {
+            const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr), j));
+            const int ij = __builtin_amdgcn_readlane(idx, j);
+            r += (pj > 0.f && (pj > pr || (pj == pr && ij < idx))) ? 1 : 0;
+          }
+          if (actp) srt[r] = pr;
+          __builtin_amdgcn_wave_barrier();
+          // cumulative sum in sorted order, in double like torch.cumsum on CPU (wave inclusive scan)
+          double cum = (lane < ns) ? (double)srt[lane] : 0.0;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(cum, o, 64);
+            if (lane >= o) cum += up;
+          }
+          const unsigned long long over = __ballot(lane < ns && (float)cum > p.top_p);
+          const int first_over = over ? (__ffsll((long long)over) - 1) : ns;      // smallest r with cum[r] > top_p
+          int keep = min(ns, first_over + 1);
+          if (ns == 0) keep = 0;
+          if (!(actp && r < keep)) lcur = -INFINITY;
+          __builtin_amdgcn_wave_barrier();
+        }
+        SSTAMP(3);
+        // ---- final softmax + multinomial as argmax(p / q) (model.py:73-82)
+        const float m2 = wave_max(lcur);
+        const float e2 = (lcur == -INFINITY) ? 0.f : expf(lcur - m2);
+        const float z2 = lane_order_sum(e2);
+        const float sc = act ? (e2 / z2) / q1 : -1.f;
+        choice = wave_argmax(sc, act ? idx : 0x7fffffff);
+      } else {
       // ---- top-p (model.py:56-70)
       if (p.top_p < 1.0f) {
         float m = -INFINITY;
@@ -309,6 +393,7 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
       }
       choice = wave_argmax(bv, bi);
     }
+      }
     SSTAMP(4);
     if (lane == 0) preds[c] = choice;
   }
