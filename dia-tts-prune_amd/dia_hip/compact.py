@@ -144,8 +144,11 @@ def pad_hidden_keep(live_hidden: torch.Tensor) -> torch.Tensor:
 
 def pad_rows(w2d: torch.Tensor, granule: int = K_GRANULE) -> torch.Tensor:
     """zero rows appended up to a multiple of `granule`: the K of o_proj after dead heads are dropped is
-    live_heads * 128 (11 heads -> 1408 rows = 44 k-tiles, which no fast kernel divides); the extra rows meet
-    activation-plane columns that nobody writes (zero), so they add exactly nothing."""
+    live_heads * 128 (11 heads -> 1408 rows = 44 k-tiles, which no fast kernel divides).  The extra rows are ZERO
+    weights; the activation-plane columns they meet are not written by this layer's attention (planes_a is shared by
+    self- and cross-attention of every layer, so they hold whatever a layer with more live heads left there): finite
+    stale values times 0.0 add exactly nothing.  Attention outputs are convex combinations of finite V rows, so the
+    planes never hold inf / nan; tests/test_gpu_kernels.py::test_padded_o_rows_ignore_stale_planes pins it."""
     pad = (-w2d.shape[0]) % granule
     if pad == 0:
         return w2d

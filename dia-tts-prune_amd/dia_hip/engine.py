@@ -60,8 +60,15 @@ class DeviceWeights:
         def dev(name):
             return sd[name].to(device=device, dtype=torch.float32)
 
+        self.max_weight_rounding = 0.0                  # largest |w - bf16(w)| / max|w| over the DenseGeneral kernels
+
         def tile(w2d) -> TiledW:
             t, kt, ns = lay.tile_weight(w2d)
+            if w2d.numel():
+                err = (w2d - w2d.to(torch.bfloat16).to(w2d.dtype)).abs().max()
+                scale = w2d.abs().max()
+                if float(scale) > 0.0:
+                    self.max_weight_rounding = max(self.max_weight_rounding, float(err / scale))
             return TiledW(t, kt, ns)
 
         perm = lay.rope_pair_perm(HEAD_DIM).to(device)

@@ -60,6 +60,7 @@ class Dia:
         self.model: Optional[DeviceWeights] = None      # resident weights (reference: DiaModel nn.Module)
         self.dac_model = None
         self.last_codes: Optional[np.ndarray] = None
+        self.weights_rounded = False
         hb.lib()                                        # fail now, not at first generate()
 
     # ------------------------------------------------------------------ loaders
@@ -73,9 +74,20 @@ class Dia:
         if unexpected:
             print(f"Warning: Unexpected keys found in checkpoint: {unexpected}")
         if missing:
+            # deliberate tightening: the reference loads with strict=False and only warns (model.py:173-177), which
+            # leaves the missing tensors at their random initialisation; listed in INTEGRATION.md
             raise RuntimeError(f"Missing keys in checkpoint: {missing}")
         with torch.cuda.device(self.device):
             self.model = DeviceWeights(self.config, sd, self.device)
+        # DenseGeneral kernels are streamed as bf16 in every mode.  A checkpoint whose values are bf16-representable
+        # (bf16-trained weights stored as fp32, the synthetic ones) loses nothing; a genuine fp32 checkpoint is rounded
+        # once at load = the reference's bfloat16 configuration, NOT its float32 path: say so instead of silently
+        # missing the 1e-3 logit bound of compute_dtype="float32".
+        self.weights_rounded = self.model.max_weight_rounding > 0.0
+        if self.weights_rounded and self.compute_dtype == torch.float32:
+            print(f"Warning: checkpoint weights are not bf16-representable (largest relative rounding "
+                  f"{self.model.max_weight_rounding:.2e}); they are streamed as bf16, so compute_dtype='float32' here means "
+                  f"fp32 activations / accumulation / K/V over bf16-rounded weights, not the reference's fp32 weights.")
 
     @classmethod
     def from_state_dict(cls, config: DiaConfig, state_dict: Dict[str, torch.Tensor],
@@ -248,39 +260,44 @@ class Dia:
         return audio.squeeze().cpu().numpy()
 
     # ------------------------------------------------------------------ audio file IO (host side)
+    # Both need third-party pieces that do not exist offline (the DAC codec, torchaudio, soundfile): row (f)-3 of
+    # SURVEY.md section 8 stays outside this build.  The methods keep the reference's names, arguments and failure
+    # behaviour (reference model.py:546-595) so that callers written against it run unchanged once a codec is attached.
     def load_audio(self, audio_path: str) -> torch.Tensor:
-        """reference model.py:546-576 — needs the codec and torchaudio."""
-        if self.dac_model is None:
+        """waveform file -> codec frames [T, C] for ``generate(audio_prompt=...)`` (mono, 44.1 kHz)."""
+        codec = self.dac_model
+        if codec is None:
             raise RuntimeError("DAC model not loaded. Cannot encode audio.")
         try:
             import torchaudio  # type: ignore
-
-            audio, sr = torchaudio.load(audio_path)
-            if audio.shape[0] > 1:
-                audio = torch.mean(audio, dim=0, keepdim=True)
-            if sr != DEFAULT_SAMPLE_RATE:
-                audio = torchaudio.functional.resample(audio, sr, DEFAULT_SAMPLE_RATE)
-            audio = audio.to(self.device).unsqueeze(0)
-            with torch.inference_mode():
-                data = self.dac_model.preprocess(audio, DEFAULT_SAMPLE_RATE)
-                _, frames, _, _, _ = self.dac_model.encode(data)
-            return frames.squeeze(0).transpose(0, 1)
+            wave, rate = torchaudio.load(audio_path)
         except FileNotFoundError:
             raise FileNotFoundError(f"Audio file not found: {audio_path}")
         except Exception as e:
             raise RuntimeError(f"Error loading or encoding audio file {audio_path}: {e}") from e
+        try:
+            mono = wave if wave.shape[0] == 1 else wave.mean(dim=0, keepdim=True)
+            if rate != DEFAULT_SAMPLE_RATE:
+                mono = torchaudio.functional.resample(mono, rate, DEFAULT_SAMPLE_RATE)
+            with torch.inference_mode():
+                prepared = codec.preprocess(mono.to(self.device)[None], DEFAULT_SAMPLE_RATE)
+                frames = codec.encode(prepared)[1]              # (z, codes, latents, ...): the codes
+            return frames[0].T.contiguous()
+        except Exception as e:
+            raise RuntimeError(f"Error loading or encoding audio file {audio_path}: {e}") from e
 
     def save_audio(self, path: str, audio: np.ndarray, sample_rate: int = DEFAULT_SAMPLE_RATE):
-        """reference model.py:578-595."""
+        """waveform -> file; failures are printed, not raised, like every failure behind ``generate``."""
         if audio is None:
             print("Warning: Cannot save None audio.")
             return
         try:
-            import soundfile as sf  # type: ignore
-
-            Path(path).parent.mkdir(parents=True, exist_ok=True)
-            if not np.issubdtype(audio.dtype, np.floating):
-                audio = audio.astype(np.float32) / np.iinfo(audio.dtype).max
-            sf.write(path, np.clip(audio, -1.0, 1.0), sample_rate)
+            import soundfile  # type: ignore
+            out = Path(path)
+            out.parent.mkdir(parents=True, exist_ok=True)
+            samples = np.asarray(audio)
+            if samples.dtype.kind in "iu":
+                samples = samples.astype(np.float32) / float(np.iinfo(samples.dtype).max)
+            soundfile.write(str(out), samples.clip(-1.0, 1.0), sample_rate)
         except Exception as e:
             print(f"Error saving audio to {path}: {e}")

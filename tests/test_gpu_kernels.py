@@ -798,3 +798,31 @@ def test_gemm_split_k_paired_strips(M, K, D, sk):
     assert (outs[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+
+
+@pytest.mark.parametrize("M", [2, 16])
+def test_padded_o_rows_ignore_stale_planes(M):
+    """compact.pad_rows: the zero rows appended to a head-pruned o_proj meet activation-plane columns that this layer's
+    attention never wrote (stale but finite leftovers of other layers).  Zero weights times finite values add exactly
+    nothing: the result is bit-identical whatever those columns hold."""
+    d = dev()
+    torch.manual_seed(17 + M)
+    live, K, D = 11 * 128, 12 * 128, 2048                       # 11 live heads, K padded to 1536
+    a = torch.randn(M, K, device=d)
+    W = bf16r(torch.randn(K, D, device=d) * 0.03)
+    W[live:] = 0                                                # the padding rows
+    x0 = torch.randn(M, D, device=d)
+    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+    Wt, kt, ns = lay.tile_weight(W)
+    mpad = (M + 15) // 16 * 16
+    outs = []
+    for stale in (0.0, 3.0e30):
+        aa = a.clone()
+        aa[:, live:] = stale
+        x = x0.clone()
+        P = torch.zeros(3, mpad // 16, D // 32, 64, 8, dtype=torch.bfloat16, device=d)
+        ssq = torch.zeros(ns, mpad, device=d)
+        run_gemm(aa, Wt, kt, ns, hb.EPI_RESID_EMIT, out=x, ldo=D, gnext=gn, P=P, p_kt=D // 32, ssq_out=ssq, ssq_ld=mpad)
+        outs.append((x, P.clone(), ssq))
+    assert torch.isfinite(outs[1][0]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])

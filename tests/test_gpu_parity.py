@@ -691,3 +691,31 @@ def test_full_size_bf16_kv_vs_oracle(full):
               f"sample agreement {agree:.3f}, free-running identical rows {prefix}/{mt}")
     assert out["f32"][0] <= LOGIT_TOL and out["f32"][1] == 1.0 and out["f32"][2] == mt
     assert out["bf16"][0] <= BF16_KV_LOGIT_BOUND_FULL and out["bf16"][1] >= 0.8
+
+
+def test_fp32_checkpoint_is_rounded_once_and_says_so(mid, capsys):
+    """A checkpoint whose weights are NOT bf16-representable (a genuine fp32 checkpoint): the DenseGeneral kernels are
+    streamed as bf16, so compute_dtype="float32" computes the reference's arithmetic over bf16-ROUNDED weights.  The load
+    says so; against the oracle on the rounded weights the 1e-3 bound holds with identical samples; against the oracle
+    on the unrounded fp32 weights the error is what weight rounding costs — measured here, documented in INTEGRATION.md."""
+    cfg, sd, _ = mid
+    g = torch.Generator().manual_seed(3)
+    raw = {k: (v + v.abs().mean() * 2.0 ** -10 * torch.randn(v.shape, generator=g)) if v.ndim >= 2 and "embedding" not in k else v.clone()
+           for k, v in sd.items()}
+    rounded = {k: (v.to(torch.bfloat16).float() if v.ndim >= 2 and "embedding" not in k else v) for k, v in raw.items()}
+    assert any(not torch.equal(raw[k], rounded[k]) for k in raw)
+    dia = Dia.from_state_dict(cfg, raw, "float32", torch.device("cuda:0"))
+    out = capsys.readouterr().out
+    assert dia.weights_rounded and "not bf16-representable" in out
+    assert not Dia.from_state_dict(cfg, sd, "float32", torch.device("cuda:0")).weights_rounded      # the synthetic ones are exact
+    mt = 24
+    r_round, nz = oracle_run(cfg, rounded, TEXTS[0], 42, mt)
+    r_raw, _ = oracle_run(cfg, raw, TEXTS[0], 42, mt, forced_tokens=r_round.tokens)
+    logits, res = teacher_forced(dia.model, cfg, [TEXTS[0]], [r_round.tokens], [nz], mt)
+    e_round = max(float(np.abs(logits[i][0] - r_round.logits[i]).max()) for i in range(len(r_round.logits)))
+    e_raw = max(float(np.abs(logits[i][0] - r_raw.logits[i]).max()) for i in range(len(r_raw.logits)))
+    print(f"fp32 checkpoint: logits vs oracle on bf16-rounded weights {e_round:.3e}, vs oracle on the fp32 weights {e_raw:.3e}")
+    assert e_round <= LOGIT_TOL
+    for i, p_ in enumerate(r_round.preds):
+        assert np.array_equal(res[0].preds[1 + i], p_), i
+    assert e_raw <= 5e-2                                        # the cost of rounding the weights once (bf16: 8 significand bits)
