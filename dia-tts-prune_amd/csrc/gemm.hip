@@ -439,6 +439,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
             stg[(2 * 16 + r16) * 16 + ecol] = *reinterpret_cast<bf16_raw*>(&ec);
           }
           lds_barrier();
+          STAMP(4);
           if (resid) {
             if (tid < 96) {
               const int pl = tid >> 5, mm = (tid & 31) >> 1, hh = tid & 1;
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) v += rf[ww * 256];
       }
+      STAMP(3);
     } else {
       reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
       STAMP(3);

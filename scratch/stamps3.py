@@ -7,7 +7,7 @@ d = torch.device("cuda:0"); L = hb.lib()
 L.dia_dbg_stamps.argtypes = [C.c_void_p, C.c_int]
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 mpad = (M + 15) // 16 * 16
-for shape, K, N, epi, sk in (("o", 2048, 2048, hb.EPI_RESID_EMIT, 0), ("wi", 2048, 16384, hb.EPI_SWIGLU_EMIT, 0), ("wo", 8192, 2048, hb.EPI_RESID_EMIT, 4), ("wo", 8192, 2048, hb.EPI_RESID_EMIT, 2)):
+for shape, K, N, epi, sk in (("o", 2048, 2048, hb.EPI_RESID_EMIT, 0), ("qkv", 2048, 3072, hb.EPI_SCALE_STORE, 0)):
     Ws = [torch.randint(-30000, 30000, (N // 16, K // 32, 64, 8), dtype=torch.int16, device=d).view(torch.bfloat16) for _ in range(6)]
     A = lay.pack_planes(torch.randn(M, K, device=d))
     ssq = torch.ones(K // 16, mpad, device=d); out = torch.zeros(mpad, N, device=d)
@@ -33,4 +33,4 @@ for shape, K, N, epi, sk in (("o", 2048, 2048, hb.EPI_RESID_EMIT, 0), ("wi", 204
         st = st[st[:, 0] > st[:, 0].max() - 5000]            # the last launch only
         t0 = st[:, 0].min(); us = (st - t0) / 100.0
         f = lambda c: f"{np.median(us[:, c]):5.2f}/{us[:, c].max():5.2f}"
-        print(f"{shape} M={M} sk={sk} rep{rep} WGs {len(st)}: start {f(0)} loads issued {f(1)} MFMA done {f(2)} " + (f"reduced {f(3)} combined {f(4)} " if sk else "") + f"end {f(5)}  (median/max us)")
+        print(f"{shape} M={M} sk={sk} rep{rep} WGs {len(st)}: start {f(0)} loads issued {f(1)} MFMA done {f(2)} " + (f"reduced {f(3)} combined {f(4)} " if sk else f"summed {f(3)} staged {f(4)} ") + f"end {f(5)}  (median/max us)")
