@@ -12,9 +12,9 @@ def _line(name):
 
 
 def test_default_bench_line_has_the_contract_keys():
-    d = _line("r01_bench_batch1.json")
+    d = _line("r02_bench_default.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "configs"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["unit"] == "frames/s" and d["dtype"] == "bf16" and d["data"] == "synthetic"
@@ -24,17 +24,39 @@ def test_default_bench_line_has_the_contract_keys():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["us_per_launch"] * 1e-6) / 1e9) < 0.01 * r["achieved"]
-    assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["bytes_per_launch"] < 1.1      # PMC traffic ~ algorithmic bytes
+    assert r["kernel_us"] <= r["us_per_launch"] and r["launches_per_step"] >= 1
+    # the dominant kernel by time heads the per-kernel table, whose shares cover the step
+    rows = d["roofline_by_kernel"]
+    assert rows[0]["kernel"] == r["kernel"] and all(rows[i]["share_of_step_time"] >= rows[i + 1]["share_of_step_time"] for i in range(len(rows) - 1))
+    assert 0.97 <= sum(x["share_of_step_time"] for x in rows) <= 1.03
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
     assert 0 < d["prefill"]["mfma_frac"] < 1 and d["prefill"]["peak_tflops_bf16_dense"] == 2500.0
+    assert abs(d["prefill"]["mfma_frac_issued"] - 3 * d["prefill"]["mfma_frac"]) < 2e-3
+    # every single-GPU BASELINE configuration rides in the same line, at 1024 steps
+    cf = d["configs"]
+    assert set(cf) == {"batch1_bf16kv", "batch1_f32kv", "batch8_mixed_bf16kv", "batch8_mixed_f32kv", "pruned50_batch8_bf16kv", "pruned50_batch1_bf16kv"}
+    for v in cf.values():
+        assert v["steps"] == 1024 and v["frames_per_s"] > 0 and 0 < v["step_frac_of_hbm_peak"] < 1
+    assert cf["pruned50_batch8_bf16kv"]["decode_weight_bytes"] < 0.45 * cf["batch8_mixed_bf16kv"]["decode_weight_bytes"]
+
+
+def test_traffic_file_names_the_kernels_of_the_bench_line():
+    """profiles/traffic.json (PMC passes) is keyed by the kernel names bench.py reports; HBM traffic of the weight streams ~ algorithmic bytes"""
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["batch1"]
+    d = _line("r02_bench_default.json")
+    by = {x["kernel"]: x for x in d["roofline_by_kernel"]}
+    for name in ("k_gemv_small<8, 8, 2, false>", "k_gemv_small<16, 4, 2, true>", "k_gemv_small<8, 16, 2, false>"):
+        assert name in t and name in by
+        assert 0.95 <= t[name]["hbm_bytes_per_launch"] / by[name]["bytes_per_launch"] <= 1.15
 
 
 def test_other_config_lines():
-    for name in ("r01_bench_batch8.json", "r01_bench_batch8_pruned50.json"):
+    for name in ("r02_bench_batch8.json", "r02_bench_batch8_pruned50.json"):
         d = _line(name)
-        assert d["config"]["batch_per_gpu"] == 8 and d["value"] > 0 and d["roofline"]["traffic"] is None
+        assert d["config"]["batch_per_gpu"] == 8 and d["value"] > 0 and d["roofline"]["kernel"]
         assert d.get("cpu_baseline") is None             # the CPU leg runs in the default (batch 1, N = 1) invocation only
+        assert "text bytes [32, 64, 96, 128, 192, 256, 384, 512]" in d["config"]["workload"]
 
 
 def test_default_batch_follows_baseline_configs():
