@@ -143,6 +143,53 @@ __device__ long long g_sstamps[16];
 #define SSTAMP(i) do {} while (0)
 #endif
 
+// ---- wave-wide reductions on DPP row operations + four v_readlane (a ds_bpermute shuffle costs an LDS round trip per step,
+// and this kernel is one dependent chain of them: 60 shuffles were 3 of its 6.7 us top-p phase)
+#define DIA_DPPI(x, ctrl) __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xF, 0xF, true)
+#define DIA_DPPF(x, ctrl) __builtin_bit_cast(float, DIA_DPPI(__builtin_bit_cast(int, (x)), (ctrl)))
+__device__ __forceinline__ float lane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float wsum(float v) {          // same value in every lane: (r0 + r1) + (r2 + r3) of the four row sums
+  v = row16_sum(v);
+  return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+}
+__device__ __forceinline__ float wmax(float v) {
+  v = fmaxf(v, DIA_DPPF(v, 0xB1));
+  v = fmaxf(v, DIA_DPPF(v, 0x4E));
+  v = fmaxf(v, DIA_DPPF(v, 0x141));
+  v = fmaxf(v, DIA_DPPF(v, 0x140));
+  return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
+}
+// (value, index) -> index of the largest value, smallest index among equals
+__device__ __forceinline__ int wargmax(float bv, int bi) {
+#define DIA_AM_STEP(ctrl) { const float ov = DIA_DPPF(bv, ctrl); const int oi = DIA_DPPI(bi, ctrl); \
+                            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; } }
+  DIA_AM_STEP(0xB1) DIA_AM_STEP(0x4E) DIA_AM_STEP(0x141) DIA_AM_STEP(0x140)
+#undef DIA_AM_STEP
+  float v = lane_f(bv, 0); int ix = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+  for (int r = 16; r < 64; r += 16) {
+    const float ov = lane_f(bv, r); const int oi = __builtin_amdgcn_readlane(bi, r);
+    if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+  }
+  return ix;
+}
+// inclusive prefix sum over the 64 lanes in double: Hillis-Steele inside each row of 16 on row_shr (lanes shifted in from
+// outside the row read 0), then the totals of the rows below
+__device__ __forceinline__ double wscan_incl(double x, int lane) {
+#define DIA_SC_STEP(n) { const int lo = DIA_DPPI(__double2loint(x), 0x110 + (n)), hi = DIA_DPPI(__double2hiint(x), 0x110 + (n)); \
+                         x += __hiloint2double(hi, lo); }
+  DIA_SC_STEP(1) DIA_SC_STEP(2) DIA_SC_STEP(4) DIA_SC_STEP(8)
+#undef DIA_SC_STEP
+  const double t0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 15), __builtin_amdgcn_readlane(__double2loint(x), 15));
+  const double t1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 31), __builtin_amdgcn_readlane(__double2loint(x), 31));
+  const double t2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 47), __builtin_amdgcn_readlane(__double2loint(x), 47));
+  const int row = lane >> 4;
+  const double below = row == 0 ? 0.0 : row == 1 ? t0 : row == 2 ? t0 + t1 : (t0 + t1) + t2;
+  return x + below;
+}
+
 __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int preds[MAXC];
@@ -151,11 +198,28 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
   const int b = blockIdx.x;
+  SSTAMP(0);
+  // the logits of this wave's channel do not depend on any device-side state: requested before cur[] / fsm[] are read,
+  // on clamped indices (no per-element branches: a conditional load makes hipcc wait for it on the spot)
+  const int cc = min(c, p.C - 1);
+  const float* un = p.logits + (long)(2 * b) * p.ld_logits + cc * p.V;
+  const float* co = p.logits + (long)(2 * b + 1) * p.ld_logits + cc * p.V;
+  float cv[NV], uv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = min(lane + 64 * i, p.V - 1);
+    cv[i] = co[v]; uv[i] = un[v];
+  }
   const int cur = p.cur[b];
   int* fsm = p.fsm + b * 8;
   const bool done = fsm[3] != 0;                    // uniform over the workgroup
   const int first = p.first_step ? p.first_step[b] : 1;
   const bool replay = cur < first;                  // audio-prompt rows: nothing sampled, nothing written
+  // what the state machine reads after the barrier, requested now (every wave: no branch around loads)
+  const int chl = min(lane, p.C - 1);
+  const int fsm_old = p.tokens[((long)b * p.T + cur) * p.C + chl];
+  const int fsm_d = p.delay[chl];
+  const int fsm0 = fsm[0], fsm1 = fsm[1], fsm2 = fsm[2];
 
   // per-wave LDS scratch for the top-p ordering
   float* lp = reinterpret_cast<float*>(smem_raw) + (size_t)c * (2 * VCAP + VCAP);  // [VCAP] probs of survivors
@@ -163,22 +227,14 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
   unsigned short* li = reinterpret_cast<unsigned short*>(sp + VCAP);                // [VCAP] survivor indices
   unsigned short* rk = li + VCAP;                                                   // [VCAP] rank by vocab index
 
-  SSTAMP(0);
+  float warm = 0.f;                                 // see "next-step embedding rows" below
   if (!done && !replay && c < p.C) {
     const int n = cur - first;                                                      // sampled steps so far
-    const float* un = p.logits + (long)(2 * b) * p.ld_logits + c * p.V;
-    const float* co = p.logits + (long)(2 * b + 1) * p.ld_logits + c * p.V;
     float lg[NV], qn[NV];
-    // every load of this wave is issued up front on clamped indices (no per-element branches: a
-    // conditional load makes hipcc wait for it on the spot), selections happen afterwards
     const bool use_noise = p.temperature != 0.0f;
     const float* q = use_noise ? p.noise + (((long)b * p.noise_steps + n) * p.C + c) * p.V : co;
-    float cv[NV], uv[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int v = min(lane + 64 * i, p.V - 1);
-      cv[i] = co[v]; uv[i] = un[v]; qn[i] = q[v];
-    }
+    for (int i = 0; i < NV; ++i) qn[i] = q[min(lane + 64 * i, p.V - 1)];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = lane + 64 * i;
@@ -196,113 +252,129 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
         const int v = lane + 64 * i;
         if (v < p.V && (bi == 0x7fffffff || lg[i] > bv)) { bv = lg[i]; bi = v; }
       }
-      choice = wave_argmax(bv, bi);
+      choice = wargmax(bv, bi);
     } else {
 #pragma unroll
       for (int i = 0; i < NV; ++i) lg[i] = lg[i] / p.temperature;                   // model.py:43
       SSTAMP(1);
-      // ---- top-k: k-th largest value by bitwise search on order-preserving keys (model.py:46-52)
-      if (p.top_k > 0) {
-        const int k = min(p.top_k, p.V);
-        uint32_t key[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) key[i] = (lane + 64 * i < p.V) ? fkey(lg[i]) : 0u;
-        uint32_t pre = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-          const uint32_t cand = pre | (1u << bit);
-          int cnt = 0;
-#pragma unroll
-          for (int i = 0; i < NV; ++i) cnt += __popcll(__ballot(key[i] >= cand));
-          if (cnt >= k) pre = cand;
-          if (cnt == k) break;          // exactly the k largest already separated: same mask as the full search
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) if (key[i] < pre) lg[i] = -INFINITY;
-      }
-      SSTAMP(2);
-      // ---- survivors of the top-k cut.  With at most 64 of them (k = 35 plus ties: the usual case) everything that
-      // follows — softmax, top-p ordering, final softmax, multinomial — runs on ONE element per lane instead of 17
-      // registers of mostly -inf.  The arithmetic is the general path's, bit for bit: the softmax denominators are
-      // accumulated per ORIGINAL lane in index order and then summed by the same butterfly (lanep[] below).
-      int nsv = 0;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) nsv += __popcll(__ballot(lg[i] != -INFINITY));
-      if (nsv >= 1 && nsv <= 64) {
-        float* lanep = lp + 128;                       // [64] per-original-lane partial sums
-        float* srt = lp + 256;                         // [64] probabilities in sorted order
+      // ---- top-k (model.py:46-52): everything below the k-th largest value goes to -inf.
+      // k <= 64 (the reference's default is 35): the k-th largest of the 64 per-lane maxima is a lower bound T0 of the
+      // k-th largest value overall (k lanes hold something >= T0), and about 47 of the 1028 values reach it.  With at
+      // most 64 candidates they are compacted to one per lane, in increasing vocabulary index, and the cut is a count of
+      // larger candidates.  More candidates than lanes, k > 64 or no top-k: the k-th value by bitwise search on
+      // order-preserving keys, and the survivors are compacted if they fit.
+      const int k = min(p.top_k, p.V);
+      bool compact = false, kcut = false;
+      int cnt = 0;
+      auto compact_if = [&](auto pred) {               // survivors of pred(lg[i]) -> lp (value), sp (noise), li (index)
         int base = 0;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {                 // compaction in increasing vocabulary index (index = 64 i + lane)
-          const unsigned long long mk = __ballot(lg[i] != -INFINITY);
-          if (lg[i] != -INFINITY) {
+        for (int i = 0; i < NV; ++i) {
+          const bool in = pred(lg[i]);
+          const unsigned long long mk = __ballot(in);
+          if (in) {
             const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
             lp[pos] = lg[i]; sp[pos] = qn[i]; li[pos] = (unsigned short)(lane + 64 * i);
           }
           base += __popcll(mk);
         }
         __builtin_amdgcn_wave_barrier();
-        const bool act = lane < nsv;
-        const float l = act ? lp[lane] : -INFINITY;
-        const float q1 = act ? sp[lane] : 1.0f;
-        const int idx = act ? (int)li[lane] : 0x7fff;
-        const int Lc = idx & 63;
-        // occurrence number of this element among the survivors of its original lane (increasing index)
-        int occ = 0;
-        for (int j = 0; j < nsv; ++j) {
-          const int lj = __builtin_amdgcn_readlane(Lc, j);
-          occ += (j < lane && lj == Lc) ? 1 : 0;
-        }
-        int maxocc = occ;
+      };
+      if (p.top_k > 0 && k <= 64) {
+        float lm = lg[0];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) maxocc = max(maxocc, __shfl_xor(maxocc, o, 64));
-        auto lane_order_sum = [&](float e) {           // sum over all elements exactly as the 17-register form does it
-          lanep[lane] = 0.f;
-          __builtin_amdgcn_wave_barrier();
-          for (int r = 0; r <= maxocc; ++r) {
-            if (act && occ == r) lanep[Lc] = lanep[Lc] + e;
-            __builtin_amdgcn_wave_barrier();
+        for (int i = 1; i < NV; ++i) lm = fmaxf(lm, lg[i]);
+        int above = 0;                                 // lanes whose maximum is larger than this lane's
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) above += (lane_f(lm, j) > lm) ? 1 : 0;
+        const float t0 = -wmax(above < k ? -lm : -INFINITY);     // smallest of the k largest lane maxima (ties included)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) cnt += __popcll(__ballot(lg[i] >= t0));
+        if (t0 != -INFINITY && cnt <= 64) {
+          compact_if([&](float x) { return x >= t0; });
+          compact = true; kcut = true;
+        }
+      }
+      if (!compact) {
+        if (p.top_k > 0) {
+          uint32_t key[NV];
+#pragma unroll
+          for (int i = 0; i < NV; ++i) key[i] = (lane + 64 * i < p.V) ? fkey(lg[i]) : 0u;
+          uint32_t pre = 0;
+          for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = pre | (1u << bit);
+            int cn = 0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) cn += __popcll(__ballot(key[i] >= cand));
+            if (cn >= k) pre = cand;
+            if (cn == k) break;          // exactly the k largest already separated: same mask as the full search
           }
-          const float zl = lanep[lane];
-          __builtin_amdgcn_wave_barrier();
-          return wave_sum(zl);
-        };
-        float lcur = l;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) if (key[i] < pre) lg[i] = -INFINITY;
+        }
+        cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) cnt += __popcll(__ballot(lg[i] != -INFINITY));
+        if (cnt >= 1 && cnt <= 64) {
+          compact_if([&](float x) { return x != -INFINITY; });
+          compact = true;
+        }
+      }
+      SSTAMP(2);
+      if (compact) {
+        // ---- one candidate per lane: softmax, top-p ordering, final softmax and the draw on single registers; sums run
+        // over the compacted lanes in the DPP tree's order
+        float* srt = lp + 256;                         // [64] probabilities in sorted order
+        const bool act0 = lane < cnt;
+        float l = act0 ? lp[lane] : -INFINITY;
+        const float q1 = act0 ? sp[lane] : 1.0f;
+        const int idx = act0 ? (int)li[lane] : 0x7fff;
+        bool act = act0;
+        if (kcut) {                                    // keep what fewer than k candidates exceed: everything >= the k-th value
+          int gt = 0;
+          for (int j = 0; j < cnt; ++j) gt += (lane_f(l, j) > l) ? 1 : 0;
+          act = act0 && gt < k;
+          if (!act) l = -INFINITY;
+        }
         if (p.top_p < 1.0f) {                          // model.py:56-70
-          const float m = wave_max(l);
+          const float m = wmax(l);
           const float e = act ? expf(l - m) : 0.f;
-          const float z = lane_order_sum(e);
+          const float z = wsum(e);
           const float pr = e / z;
           const bool actp = act && pr > 0.f;           // (a survivor whose probability underflows sorts after everything)
           const int ns = __popcll(__ballot(actp));
-          int r = 0;
-          for (int j = 0; j < nsv; ++j) {
-            const float pj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr), j));
-            const int ij = __builtin_amdgcn_readlane(idx, j);
-            r += (pj > 0.f && (pj > pr || (pj == pr && ij < idx))) ? 1 : 0;
+          int r = 0, eq = 0;                           // rank by descending probability; equal ones by index, if there are any
+          for (int j = 0; j < cnt; ++j) {
+            const float pj = lane_f(pr, j);
+            r += (pj > pr) ? 1 : 0;
+            eq += (pj == pr) ? 1 : 0;
+          }
+          if (__ballot(actp && eq > 1)) {
+            for (int j = 0; j < cnt; ++j) {
+              const float pj = lane_f(pr, j);
+              const int ij = __builtin_amdgcn_readlane(idx, j);
+              r += (pj == pr && ij < idx) ? 1 : 0;
+            }
           }
           if (actp) srt[r] = pr;
           __builtin_amdgcn_wave_barrier();
-          // cumulative sum in sorted order, in double like torch.cumsum on CPU (wave inclusive scan)
-          double cum = (lane < ns) ? (double)srt[lane] : 0.0;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const double up = __shfl_up(cum, o, 64);
-            if (lane >= o) cum += up;
-          }
+          // cumulative sum in sorted order, in double like torch.cumsum on CPU — in double the scan order moves the
+          // sum by ~1e-16 relative, far below the fp32 rounding applied before the comparison
+          const double cum = wscan_incl((lane < ns) ? (double)srt[lane] : 0.0, lane);
           const unsigned long long over = __ballot(lane < ns && (float)cum > p.top_p);
           const int first_over = over ? (__ffsll((long long)over) - 1) : ns;      // smallest r with cum[r] > top_p
-          int keep = min(ns, first_over + 1);
+          int keep = min(ns, first_over + 1);          // entry r+1 is removed iff float(cum[r]) > top_p; monotone in r
           if (ns == 0) keep = 0;
-          if (!(actp && r < keep)) lcur = -INFINITY;
+          if (!(actp && r < keep)) l = -INFINITY;
           __builtin_amdgcn_wave_barrier();
         }
         SSTAMP(3);
         // ---- final softmax + multinomial as argmax(p / q) (model.py:73-82)
-        const float m2 = wave_max(lcur);
-        const float e2 = (lcur == -INFINITY) ? 0.f : expf(lcur - m2);
-        const float z2 = lane_order_sum(e2);
+        const float m2 = wmax(l);
+        const float e2 = (l == -INFINITY) ? 0.f : expf(l - m2);
+        const float z2 = wsum(e2);
         const float sc = act ? (e2 / z2) / q1 : -1.f;
-        choice = wave_argmax(sc, act ? idx : 0x7fffffff);
+        choice = wargmax(sc, act ? idx : 0x7fffffff);
       } else {
       // ---- top-p (model.py:56-70)
       if (p.top_p < 1.0f) {
@@ -396,6 +468,11 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
       }
     SSTAMP(4);
     if (lane == 0) preds[c] = choice;
+    // next-step embedding rows: outside the EOS countdown and the BOS window the token written is the one just drawn, so
+    // this wave pulls its channel's row (one dword per 64-byte line) towards the L2 of this XCD while the other waves
+    // finish and the state machine runs; embed_rows() below then finds it there instead of in HBM
+    const float* row = p.e.emb + ((long)c * p.e.V + choice) * p.e.D;
+    for (int o = lane * 16; o < p.e.D; o += 64 * 16) warm += row[o];
   }
   __syncthreads();
 
@@ -407,9 +484,9 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
       const bool ch = lane < p.C;
       int* prow = p.pred + ((long)b * p.T + cur) * p.C;
       int* trow = p.tokens + ((long)b * p.T + cur) * p.C;
-      int eos_detected = fsm[0], eos_countdown = fsm[1], bos_countdown = fsm[2];      // same address in every lane
-      const int old = ch ? trow[lane] : 0;
-      const int d = ch ? p.delay[lane] : 0;
+      int eos_detected = fsm0, eos_countdown = fsm1, bos_countdown = fsm2;            // read before the sampling started
+      const int old = ch ? fsm_old : 0;
+      const int d = ch ? fsm_d : 0;
       int pr = (ch && !replay) ? preds[lane] : -1;
       if (ch && !replay) prow[lane] = pr;
       const int pr0 = __shfl(pr, 0, 64);
@@ -439,7 +516,7 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
         fsm[0] = eos_detected; fsm[1] = eos_countdown; fsm[2] = bos_countdown; fsm[3] = finished; fsm[4] = last;
       }
     }
-    if (lane == 0) go_next = go;
+    if (lane == 0) go_next = go && !(warm == 1.2345e38f);      // (keeps the warm-up loads alive; never true)
   }
   __syncthreads();
   SSTAMP(6);

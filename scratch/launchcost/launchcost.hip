@@ -61,6 +61,46 @@ __global__ void k_gemvlike(const u4* w, const u4* a_in, u4* a_out, float* out, i
   } else if (s == 0x12345678u) out[blockIdx.x] = 1.f;
 }
 
+// (h) with the stream and the operand sized by template: NL 16-byte weight loads per thread (8 = 64 KB per workgroup,
+// 4 = 32 KB: "half strips" on twice the workgroups), NI 16-byte operand loads per thread (3 = 24 KB = three bf16 planes
+// of 2 x 2048 values, 2 = 16 KB = the same values as fp32)
+template <int NL, int NI>
+__global__ void k_gemvlike_sized(const u4* w, const u4* a_in, u4* a_out, float* out, int per_wg) {
+  __shared__ u4 As[512 * NI];
+  __shared__ float red[8][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  u4 av[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) av[i] = a_in[tid + 512 * i];
+  const u4* base = w + (size_t)blockIdx.x * per_wg + tid;
+  u4 v[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) v[i] = __builtin_nontemporal_load(base + i * 512);
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) As[tid + 512 * i] = av[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { const u4 t = As[(tid * 7 + 512 * i + 13) % (512 * NI)]; s += t.x ^ t.w; }
+#pragma unroll
+  for (int i = 0; i < NL; ++i) s += v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+  red[wv][lane] = (float)s;
+  __syncthreads();
+  if (tid < 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += red[k][tid];
+    red[0][tid] = a;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const float x = red[0][tid] + red[0][tid + 32];
+    const unsigned xb = __float_as_uint(x) | 1u;
+    const u4 o = {xb, xb + 1, xb + 2, xb + 3};
+    if (tid < 12) a_out[(blockIdx.x % 128) * 12 + tid] = o;
+  }
+}
+
 // (h) again with the real kernel's resource footprint: dynamic LDS and a forced VGPR allocation
 template <int F>
 __global__ __attribute__((amdgpu_num_vgpr(128))) void k_gemvlike_fat(const u4* w, const u4* a_in, u4* a_out, float* out, int per_wg) {
@@ -164,7 +204,7 @@ int run(const char* name, hipStream_t st, int n, F launch) {
 
 int main() {
   hipStream_t st; CK(hipStreamCreate(&st));
-  u4* big; CK(hipMalloc(&big, 512u << 20)); CK(hipMemset(big, 1, 512u << 20));   // 64 x 8 MB: beyond L2 + Infinity Cache
+  u4* big; CK(hipMalloc(&big, 544u << 20)); CK(hipMemset(big, 1, 544u << 20));   // 64 x 8 MB: beyond L2 + Infinity Cache
   float* out; CK(hipMalloc(&out, 1 << 20));
   u4 *a0, *a1; CK(hipMalloc(&a0, 24576)); CK(hipMalloc(&a1, 24576)); CK(hipMemset(a0, 1, 24576)); CK(hipMemset(a1, 1, 24576));
   int* dummy = nullptr;
@@ -184,6 +224,14 @@ int main() {
   if (run("(l) (k) with 60 KB of dynamic LDS", st, N, [&](int i) { hipLaunchKernelGGL(k_gemvlike_fat<7>, dim3(128), dim3(512), 61440, st, wb(i), (i & 1) ? a1 : a0, (i & 1) ? a0 : a1, out, 4096); })) return 1;
   // (j): 256 workgroups read 16 MB per launch — 32 distinct 16 MB windows of the same 512 MB buffer
   if (run("(j) (h) with 256 workgroups, 16 MB", st, N, [&](int i) { hipLaunchKernelGGL(k_gemvlike<7>, dim3(256), dim3(512), 0, st, big + (size_t)(i % 32) * ((16u << 20) / 16), (i & 1) ? a1 : a0, (i & 1) ? a0 : a1, out, 4096); })) return 1;
+#define RUNS(name, NL, NI, grid) if (run(name, st, N, [&](int i) { hipLaunchKernelGGL((k_gemvlike_sized<NL, NI>), dim3(grid), dim3(512), 0, st, wb(i), (i & 1) ? a1 : a0, (i & 1) ? a0 : a1, out, 512 * NL); })) return 1
+  RUNS("(m) (h) again: 128 x 64 KB weights, 24 KB operand", 8, 3, 128);
+  RUNS("(n) 128 x 64 KB weights, 16 KB operand (fp32 instead of 3 planes)", 8, 2, 128);
+  RUNS("(o) 256 x 32 KB weights (half strips), 24 KB operand", 4, 3, 256);
+  RUNS("(p) 256 x 32 KB weights (half strips), 16 KB operand", 4, 2, 256);
+  RUNS("(q) 256 x 32 KB weights, 8 KB operand", 4, 1, 256);
+  RUNS("(r) 192 x 64 KB weights (qkv), 24 KB operand", 8, 3, 192);
+  RUNS("(s) 192 x 64 KB weights (qkv), 16 KB operand", 8, 2, 192);
   {   // stamped skeleton: a few back-to-back launches, the last one's timeline (100 MHz clock)
     long long* st_d; CK(hipMalloc(&st_d, 128 * 4 * sizeof(long long)));
     for (int i = 0; i < 6; ++i) hipLaunchKernelGGL(k_gemvlike_stamped, dim3(128), dim3(512), 0, st, wb(i), (i & 1) ? a1 : a0, (i & 1) ? a0 : a1, out, 4096, st_d);
