@@ -21,13 +21,15 @@ static hsa_status_t on_agent(hsa_agent_t a, void*) {
   if (t == HSA_DEVICE_TYPE_CPU && !g_have_cpu) { g_cpu = a; g_have_cpu = true; }
   return HSA_STATUS_SUCCESS;
 }
-static hsa_amd_memory_pool_t g_dev_pool, g_karg_pool; static bool g_have_dev = false, g_have_karg = false;
+static hsa_amd_memory_pool_t g_dev_pool, g_karg_pool, g_fine_pool, g_ext_pool; static bool g_have_dev = false, g_have_karg = false, g_have_fine = false, g_have_ext = false;
 static hsa_status_t on_gpu_pool(hsa_amd_memory_pool_t p, void*) {
   hsa_amd_segment_t seg; hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
   if (seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
   uint32_t fl; hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &fl);
   bool alloc = false; hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
   if (alloc && (fl & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && !g_have_dev) { g_dev_pool = p; g_have_dev = true; }
+  if (alloc && (fl & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_EXTENDED_SCOPE_FINE_GRAINED) && !g_have_ext) { g_ext_pool = p; g_have_ext = true; }
+  else if (alloc && (fl & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_FINE_GRAINED) && !g_have_fine) { g_fine_pool = p; g_have_fine = true; }
   return HSA_STATUS_SUCCESS;
 }
 static hsa_status_t on_cpu_pool(hsa_amd_memory_pool_t p, void*) {
@@ -88,8 +90,8 @@ int main(int argc, char** argv) {
   hsa_executable_t ex; CK(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &ex));
   CK(hsa_executable_load_agent_code_object(ex, g_gpu, rd, nullptr, nullptr));
   CK(hsa_executable_freeze(ex, nullptr));
-  Kern k_empty, k_fill, k_pp, k_pp1;
-  if (get_kernel(ex, "k_empty", k_empty) || get_kernel(ex, "k_fill", k_fill) || get_kernel(ex, "k_pingpong", k_pp) || get_kernel(ex, "k_pingpong_sc1", k_pp1)) return 1;
+  Kern k_empty, k_fill, k_pp, k_pp1, k_gv, k_gvw;
+  if (get_kernel(ex, "k_empty", k_empty) || get_kernel(ex, "k_fill", k_fill) || get_kernel(ex, "k_pingpong", k_pp) || get_kernel(ex, "k_pingpong_sc1", k_pp1) || get_kernel(ex, "k_gemvlike", k_gv) || get_kernel(ex, "k_gemvlike_wt", k_gvw)) return 1;
 
   const int N = 146, REPS = 20, TOT = N * REPS;
   // kernel arguments are staged on the host and copied into DEVICE memory before each chain: with the argument blocks in
@@ -101,13 +103,21 @@ int main(int argc, char** argv) {
   unsigned* err; CK(hsa_amd_memory_pool_allocate(g_karg_pool, 4096, 0, (void**)&err));
   CK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, err));
   unsigned *a0, *a1; CK(hsa_amd_memory_pool_allocate(g_dev_pool, 24576, 0, (void**)&a0)); CK(hsa_amd_memory_pool_allocate(g_dev_pool, 24576, 0, (void**)&a1));
+  // the same operand pair in the device's fine-grained and extended-scope fine-grained ("uncached", hipDeviceMallocUncached) pools
+  unsigned *f0 = nullptr, *f1 = nullptr, *u0 = nullptr, *u1 = nullptr;
+  if (g_have_fine) { CK(hsa_amd_memory_pool_allocate(g_fine_pool, 24576, 0, (void**)&f0)); CK(hsa_amd_memory_pool_allocate(g_fine_pool, 24576, 0, (void**)&f1)); }
+  if (g_have_ext) { CK(hsa_amd_memory_pool_allocate(g_ext_pool, 24576, 0, (void**)&u0)); CK(hsa_amd_memory_pool_allocate(g_ext_pool, 24576, 0, (void**)&u1)); }
+  printf("device pools: fine-grained %d, extended-scope fine-grained %d\n", (int)g_have_fine, (int)g_have_ext);
+  unsigned *c0 = a0, *c1 = a1;
+  char* big; CK(hsa_amd_memory_pool_allocate(g_dev_pool, (size_t)512 << 20, 0, (void**)&big));      // 64 x 8 MB of weights: HBM-cold
   hsa_signal_t done; CK(hsa_signal_create(1, 0, nullptr, &done));
   const hsa_signal_t none = {0};
 
   struct PP { const unsigned* in; unsigned* out; unsigned* err; unsigned step; };
   struct Fill { unsigned* a; unsigned v; };
   const char* scope[3] = {"none", "agent", "system"};
-  auto chain = [&](const char* what, const Kern& k, uint32_t grid, uint32_t wg, int barrier, int acq, int rel, bool pp) -> int {
+  struct GV { const void* w; const void* a_in; void* a_out; };
+  auto chain = [&](const char* what, const Kern& k, uint32_t grid, uint32_t wg, int barrier, int acq, int rel, bool pp, bool gv = false) -> int {
     *err = 0;
     if (pp) {   // operand a0 = 0 everywhere (system-scope fences around the fill)
       Fill* fa = reinterpret_cast<Fill*>(kargs + (size_t)TOT * 256); fa->a = a0; fa->v = 0;
@@ -118,6 +128,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < TOT; ++i) {
       void* ka = kargs + (size_t)i * 256;
       if (pp) { PP* p = reinterpret_cast<PP*>(ka); p->in = (i & 1) ? a1 : a0; p->out = (i & 1) ? a0 : a1; p->err = err; p->step = (unsigned)i; }
+      else if (gv) { GV* p = reinterpret_cast<GV*>(ka); p->w = big + (size_t)(i % 64) * (8u << 20); p->a_in = (i & 1) ? a1 : a0; p->a_out = (i & 1) ? a0 : a1; }
       else *reinterpret_cast<int**>(ka) = nullptr;
     }
     CK(hsa_memory_copy(kargs_dev, kargs, (size_t)TOT * 256));
@@ -142,6 +153,25 @@ int main(int argc, char** argv) {
     chain("ping-pong 128 x 256, plain ld/st", k_pp, 128, 256, 1, 1, 0, true);
     chain("ping-pong 128 x 256, plain ld/st", k_pp, 128, 256, 1, 0, 1, true);
     for (int s = 2; s >= 0; --s) chain("ping-pong 128 x 256, sc1 ld/st", k_pp1, 128, 256, 1, s, s, true);
+    for (int kind = 0; kind < 2; ++kind) {      // operands in fine-grained / uncached device memory, plain loads and stores
+      unsigned* p0 = kind ? u0 : f0; unsigned* p1 = kind ? u1 : f1;
+      if (!p0) continue;
+      a0 = p0; a1 = p1;
+      const char* nm = kind ? "ping-pong plain, UNCACHED operand" : "ping-pong plain, FINE-GRAINED op.";
+      chain(nm, k_pp, 128, 256, 1, 1, 1, true);
+      chain(nm, k_pp, 128, 256, 1, 0, 0, true);
+      const char* ng = kind ? "GEMV skeleton, UNCACHED operand" : "GEMV skeleton, FINE-GRAINED operand";
+      chain(ng, k_gv, 128, 512, 1, 1, 1, false, true);
+      chain(ng, k_gv, 128, 512, 1, 0, 0, false, true);
+      a0 = c0; a1 = c1;
+    }
+    chain("GEMV skeleton, sc1 store + wait", k_gvw, 128, 512, 1, 1, 1, false, true);
+    chain("GEMV skeleton, sc1 store + wait", k_gvw, 128, 512, 1, 1, 0, false, true);
+    chain("GEMV skeleton, sc1 store + wait", k_gvw, 128, 512, 1, 0, 0, false, true);
+    for (int s = 2; s >= 1; --s) chain("GEMV skeleton 128 x 512, 8 MB", k_gv, 128, 512, 1, s, s, false, true);
+    chain("GEMV skeleton 128 x 512, 8 MB", k_gv, 128, 512, 1, 0, 1, false, true);
+    chain("GEMV skeleton 128 x 512, 8 MB", k_gv, 128, 512, 1, 1, 0, false, true);
+    chain("GEMV skeleton 128 x 512, 8 MB", k_gv, 128, 512, 1, 0, 0, false, true);
   }
   hsa_queue_destroy(g_q);
   hsa_shut_down();

@@ -188,6 +188,50 @@ def chunk_goldens():
     print("ref_chunks.npz written")
 
 
+EFFTEXT_CASES = [
+    (TEXT, None), (TEXT_SHORT, None), ("no tags at all", None), ("[S2] starts with two [S1]", None),
+    ("[S1] ends with tag [S2]", None), ("[S1] ends with its own tag [S1]", None), ("  [S1] padded with blanks.  ", None),
+    ("[S1] unicode \u00e9\u00e8 \u4f60\u597d [S2] ok", None), ("x" * 300, None), ("[S1]", None), ("[S2]", None),
+    ("[S1] one [S1] two [S1] three", None), ("[S2] a [S1] b [S2] c [S1]", None), ("[s1] lower-case tags are text", None),
+    ("[S1] Second half of a dialogue.", "[S1] Prompt transcript. [S2] With two turns."),
+    (" [S2] reply. ", "  [S1] blanks around the prompt  "), ("tail without tags", "[S2] prompt ends here"),
+]
+
+
+def efftext_goldens(M, RC, C, O):
+    """The prompt assembly inside Dia.generate (reference model.py:686-696) is inline code: pin it by calling the reference's
+    generate() with _prepare_generation replaced by a recorder that keeps the effective text it is handed and stops there;
+    the ids are the reference's own _prepare_text_input of that string."""
+    cfg = C.tiny_config()
+    cfg_ref = RC.DiaConfig.model_validate(C.config_to_json_dict(cfg))
+    dia = M.Dia(cfg_ref, "float32", torch.device("cpu"))
+
+    class Stop(Exception):
+        pass
+    seen = {}
+
+    def recorder(text, audio_prompt, verbose):
+        seen["text"] = text
+        raise Stop()
+    dia._prepare_generation = recorder
+    rec = {"n": np.int32(len(EFFTEXT_CASES))}
+    for i, (t, pt) in enumerate(EFFTEXT_CASES):
+        try:
+            dia.generate(t, max_tokens=4, audio_prompt_text=pt, seed=1)
+        except Stop:
+            pass
+        eff = seen.pop("text")
+        ids = dia._prepare_text_input(eff)[0].numpy()
+        assert eff == O.effective_text(t, pt), (t, pt, eff, O.effective_text(t, pt))
+        assert np.array_equal(ids, O.text_tokens(eff, O.Dims.of(cfg)))
+        rec[f"text_{i}"] = np.array(t)
+        rec[f"ptext_{i}"] = np.array("" if pt is None else pt)
+        rec[f"eff_{i}"] = np.array(eff)
+        rec[f"ids_{i}"] = ids.astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "ref_efftext.npz"), **rec)
+    print(f"[efftext] {len(EFFTEXT_CASES)} prompt-assembly cases pinned on the reference's generate()")
+
+
 def main():
     torch.set_num_threads(1)
     from dia_hip import config as C
@@ -196,6 +240,9 @@ def main():
 
     M, L, S = import_reference()
     import dia.config as RC
+    efftext_goldens(M, RC, C, O)
+    if "--only-efftext" in sys.argv:
+        return
     prompt_goldens(M, RC, C, O)
     chunk_goldens()
     unstructured_goldens(M, RC, C)

@@ -539,6 +539,38 @@ def test_sampler_matches_reference_cases(golden):
         assert np.array_equal(pred, g[f"out_{i}"]), (i, pred, g[f"out_{i}"])
 
 
+@pytest.mark.parametrize("quantized", [False, True])
+def test_sampler_randomized_vs_oracle(quantized):
+    """Random logits through every route of the device sampler — the lane-maxima candidate cut (k <= 64, <= 64 candidates),
+    the bitwise k-th-value search (k > 64, or more candidates than lanes), the one-per-lane path and the 17-register path
+    (no top-k), top-p off — against the oracle's sample_next_token (itself pinned on the reference's function).
+    `quantized`: logits on a 1/4 grid, so equal values and equal probabilities are everywhere (index order breaks them)."""
+    from oracle import dia_oracle as O
+    d = dev()
+    g = torch.Generator().manual_seed(11 if quantized else 7)
+    B, C_, V = 16, 9, 1028
+    cases = [(1.3, 0.95, 35), (1.0, 0.5, 10), (0.7, 1.0, 0), (1.3, 0.9, 0), (2.0, 0.3, 50), (1.0, 0.95, 64), (1.3, 0.8, 100),
+             (0.5, 0.95, 1), (1.3, 1.0, 35), (1.7, 0.99, 63), (1.0, 0.6, 5)]
+    bad = []
+    for T_, tp, tk in cases:
+        lg = torch.randn(B, C_, V, generator=g) * float(torch.empty(1).uniform_(0.5, 4.0, generator=g))
+        if quantized:
+            lg = (lg * 4).round() / 4
+        noise = torch.empty(B, 1, C_, V).exponential_(1.0, generator=g)
+        rows = torch.stack([lg, lg], dim=1).reshape(2 * B, C_, V).to(d)          # uncond == cond, cfg_scale 0
+        s, keep = _sampler_session(B, 8, C_, V, 64, rows, noise.to(d), temperature=T_, top_p=tp, top_k=tk, ignore_eos=1, max_tokens=8)
+        hb.check(hb.lib().dia_sample(C.byref(s), None), "dia_sample")
+        torch.cuda.synchronize()
+        pred = keep[2][:, 1].cpu()
+        masked = lg.clone()
+        masked[:, :, 1025] = -math.inf; masked[:, :, 1026] = -math.inf         # PAD, BOS (model.py:466-472); 1027 stays a candidate
+        masked[:, 1:, 1024] = -math.inf                                        # EOS only on channel 0
+        want = O.sample_next_token(masked, T_, tp, tk if tk > 0 else None, noise=noise[:, 0])
+        if not torch.equal(pred.long(), want.long()):
+            bad.append((T_, tp, tk, int((pred.long() != want.long()).sum())))
+    assert not bad, bad
+
+
 def test_sampler_fsm_and_embedding():
     """EOS countdown / masked write / next-step embedding against a direct restatement of
     model.py:771-807 + layers.py:691-696."""

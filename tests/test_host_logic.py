@@ -25,6 +25,19 @@ def test_text_helpers_match_reference(golden):
     assert step == int(g["prefill_step"]) and np.array_equal(pre, g["prefill"])
 
 
+def test_prompt_assembly_matches_reference_generate(golden):
+    """ref_efftext.npz: the effective text the REFERENCE's generate() hands to _prepare_generation (model.py:686-696 is inline
+    code there) for 17 tag / blank / prompt-transcript cases, and the reference's ids of it"""
+    g = golden("ref_efftext.npz")
+    cfg = C.tiny_config()
+    assert int(g["n"]) >= 17
+    for i in range(int(g["n"])):
+        pt = str(g[f"ptext_{i}"]) or None
+        eff = T.effective_text(str(g[f"text_{i}"]), pt)
+        assert eff == str(g[f"eff_{i}"]), i
+        assert np.array_equal(T.padded_text_ids(T.encode_text(eff, cfg), cfg), g[f"ids_{i}"]), i
+
+
 def test_effective_text_edges():
     assert T.effective_text("") == ""
     assert T.effective_text("  hello ") == "hello [S2]"

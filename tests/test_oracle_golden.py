@@ -80,6 +80,15 @@ def test_text_prep(golden):
     assert step == int(g["prefill_step"]) and np.array_equal(pre, g["prefill"])
 
 
+def test_prompt_assembly_pinned_on_reference_generate(golden):
+    g = golden("ref_efftext.npz")
+    dm = O.Dims.of(C.tiny_config())
+    for i in range(int(g["n"])):
+        eff = O.effective_text(str(g[f"text_{i}"]), str(g[f"ptext_{i}"]) or None)
+        assert eff == str(g[f"eff_{i}"]), i
+        assert np.array_equal(O.text_tokens(eff, dm), g[f"ids_{i}"]), i
+
+
 def test_pruned_model(golden):
     g = golden("ref_pruned_mid.npz")
     from dia_hip.pruning import structured_prune_state_dict
