@@ -544,8 +544,14 @@ def test_sampler_randomized_vs_oracle(quantized):
     """Random logits through every route of the device sampler — the lane-maxima candidate cut (k <= 64, <= 64 candidates),
     the bitwise k-th-value search (k > 64, or more candidates than lanes), the one-per-lane path and the 17-register path
     (no top-k), top-p off — against the oracle's sample_next_token (itself pinned on the reference's function).
-    `quantized`: logits on a 1/4 grid, so equal values and equal probabilities are everywhere (index order breaks them)."""
+    `quantized`: logits on a 1/4 grid, so equal values and equal probabilities are everywhere.  Equal probabilities at the
+    top-p boundary are the one place where the reference is not a function of its inputs alone (torch.sort(descending=True)
+    on CPU is not stable: ties come out in an order of its own); the device breaks them by vocabulary index, so that
+    variant is compared with the oracle under a STABLE sort."""
+    from unittest import mock
     from oracle import dia_oracle as O
+    real_sort = torch.sort
+    stable_sort = lambda t, **kw: real_sort(t, stable=True, **kw)
     d = dev()
     g = torch.Generator().manual_seed(11 if quantized else 7)
     B, C_, V = 16, 9, 1028
@@ -556,7 +562,8 @@ def test_sampler_randomized_vs_oracle(quantized):
         lg = torch.randn(B, C_, V, generator=g) * float(torch.empty(1).uniform_(0.5, 4.0, generator=g))
         if quantized:
             lg = (lg * 4).round() / 4
-        noise = torch.empty(B, 1, C_, V).exponential_(1.0, generator=g)
+        noise = torch.ones(B, 7, C_, V)                                         # max_tokens - 1 steps; step 0 is the one drawn
+        noise[:, 0] = torch.empty(B, C_, V).exponential_(1.0, generator=g)
         rows = torch.stack([lg, lg], dim=1).reshape(2 * B, C_, V).to(d)          # uncond == cond, cfg_scale 0
         s, keep = _sampler_session(B, 8, C_, V, 64, rows, noise.to(d), temperature=T_, top_p=tp, top_k=tk, ignore_eos=1, max_tokens=8)
         hb.check(hb.lib().dia_sample(C.byref(s), None), "dia_sample")
@@ -565,7 +572,8 @@ def test_sampler_randomized_vs_oracle(quantized):
         masked = lg.clone()
         masked[:, :, 1025] = -math.inf; masked[:, :, 1026] = -math.inf         # PAD, BOS (model.py:466-472); 1027 stays a candidate
         masked[:, 1:, 1024] = -math.inf                                        # EOS only on channel 0
-        want = O.sample_next_token(masked, T_, tp, tk if tk > 0 else None, noise=noise[:, 0])
+        with mock.patch.object(torch, "sort", stable_sort if quantized else real_sort):
+            want = O.sample_next_token(masked, T_, tp, tk if tk > 0 else None, noise=noise[:, 0])
         if not torch.equal(pred.long(), want.long()):
             bad.append((T_, tp, tk, int((pred.long() != want.long()).sum())))
     assert not bad, bad
