@@ -6,14 +6,15 @@
 #include <string>
 
 static const char* const k_names[DIA_TUNE_COUNT] = {
-    "attn_nz", "attn_gpw", "attn_gpw_cross", "gemm_spw", "gemm_mz_max", "tile_min_blocks", "wo_sk", "wo_pair", "wo_nw", "wo_spw",
+    "attn_nz", "attn_gpw", "attn_gpw_cross", "gemm_spw", "gemm_mz_max", "tile_min_blocks", "wo_sk", "wo_pair", "wo_nw", "wo_spw", "act_f32",
     "mlp_fuse", "tile_v", "blk32_kr", "blk32_ws", "no_g32", "g32_all", "g32m"};
-static int g_tune[DIA_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static int g_tune[DIA_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 int dia_tune(int id) { return (id >= 0 && id < DIA_TUNE_COUNT) ? g_tune[id] : -1; }
 
 extern "C" int dia_set_tuning(const char* name, int value) {
   if (!name) return dia_fail(DIA_E_ARG, "dia_set_tuning: null name");
+  dia_tuning_init_from_env();       // (an explicit setting must not be overwritten by a later first read of DIA_TUNE)
   for (int i = 0; i < DIA_TUNE_COUNT; ++i)
     if (strcmp(name, k_names[i]) == 0) { g_tune[i] = value < 0 ? -1 : value; return DIA_OK; }
   return dia_fail(DIA_E_ARG, "dia_set_tuning: unknown knob");
@@ -21,6 +22,7 @@ extern "C" int dia_set_tuning(const char* name, int value) {
 
 extern "C" int dia_get_tuning(const char* name) {
   if (!name) return -1;
+  dia_tuning_init_from_env();
   for (int i = 0; i < DIA_TUNE_COUNT; ++i)
     if (strcmp(name, k_names[i]) == 0) return g_tune[i];
   return -1;
