@@ -46,6 +46,7 @@ P = torch.zeros(3, mpad // 16, max(N // 32, 1) if epi != hb.EPI_SWIGLU_EMIT else
 ssq_out = torch.zeros(N // 16, mpad, device=d)
 gn = torch.ones(N, device=d)
 L = hb.lib()
+hb.get_tuning("act_f32")          # (reads DIA_TUNE: nothing else in this script initialises the tuning table)
 st = torch.cuda.Stream()
 skscr = torch.zeros(2 * (N // 16) * 8 * 256, device=d); sktk = torch.zeros(2 * (N // 16), dtype=torch.int32, device=d)
 lendscr = torch.zeros((N // 16) * (K // 256) * 512, device=d) if a.lend else None
