@@ -71,11 +71,6 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   const long xs = mt * xkt * 512, as = mt * akt * 512, hs = mt * hkt * 512;   // plane strides (elements)
   const int nqkv = (d.q_heads + 2 * d.kv_heads) * 128;
   int n = 0, rc;
-  // activation format per producer -> consumer edge (common.hpp): fp32 tiles from 5 rows on, except into wi — its persistent
-  // workgroups amortise the activation image over four strips, and the in-register plane split then costs more than the
-  // 64 KB save (16.8 -> 17.1 us at 16 rows; o 5.4 -> 5.1, qkv 5.8 -> 5.1, wo 14.0 -> 13.4)
-  const int F = d.act_f32 ? 1 : 0;
-  const int WI = (F && dia_tune(DIA_TUNE_ACT_F32) >= 2) ? 1 : 0;
   // 17..32 rows: every GEMM may split K inside dia_gemm (k_gemm32 / k_gemm32m) when it is handed the scratch
   const bool two_tiles = R > 16 && R <= 32 && d.sk_scratch && d.sk_tickets && d.sk_scratch_floats > 0;   // (k_gemm32 / k_gemm32m / blk32 only)
   auto lend_scratch = [&](dia_gemm_args& g) {
@@ -91,7 +86,6 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
     g.out = d.qkv; g.ldo = nqkv; g.strip_map = L.smap_qkv;
     lend_scratch(g);
-  g.act_f32 = F;            // reads x as fp32 tiles
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     dia_attn_args a = {};
@@ -101,7 +95,6 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     a.head_map = L.hmap_self; a.v_blocked = d.v_blocked; a.rope_rows = d.T + 1;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
     a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
-    a.act_f32 = F;
     if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
 
     // o_proj + residual; emits the pre-CA-normed planes (layers.py:341-343, 555, 560)
@@ -111,7 +104,6 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_ca; g.cmap = L.cmap_ca;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     lend_scratch(g);
-  g.act_f32 = 3 * F;        // attention output in, x out: both fp32 tiles
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // cross-attention query (layers.py:273, 278)
@@ -121,7 +113,6 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
     g.out = d.qc; g.ldo = d.cq_heads * 128; g.strip_map = L.smap_cq;
     lend_scratch(g);
-  g.act_f32 = F;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     a = {};
@@ -130,7 +121,6 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     a.kc = L.k_cross; a.vc = L.v_cross; a.cur = d.sample.cur; a.len = d.text_len; a.head_map = L.hmap_cross; a.v_blocked = d.v_blocked;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
     a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
-    a.act_f32 = F;
     if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
 
     g = {};
@@ -139,7 +129,6 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_mlp; g.cmap = L.cmap_mlp;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     lend_scratch(g);
-  g.act_f32 = F | (WI << 1); // x out in the format wi reads
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // SwiGLU MLP (layers.py:95-104)
@@ -194,7 +183,6 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
       e->mlp_fused = 0;                      // not available for this model: do not try again
     }
     lend_scratch(gi);
-    gi.act_f32 = WI | (F << 1); g.act_f32 = 3 * F;       // wi: x in (planes by default), hidden out; wo: hidden in, x out
     if ((rc = dia_gemm(&gi, st))) return rc; mark(e, n++);
     rc = dia_gemm(&g, st);
     if (rc == DIA_E_ARG && g.sk > 1) {
@@ -212,7 +200,6 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
   g.out = d.logits; g.ldo = d.ld_logits;
   lend_scratch(g);
-  g.act_f32 = F;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
   if (with_sampler) {
     if ((rc = dia_sample(&d.sample, st))) return rc; mark(e, n++);
@@ -227,9 +214,6 @@ extern "C" int dia_engine_create(const dia_engine_desc* d, void* stream, dia_eng
   if (d->D % 32 != 0 || d->F % 32 != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: D and F must be multiples of 32");
   if (d->rows_pad < 2 * d->B || d->rows_pad % 16 != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: rows_pad must be 16*ceil(2B/16)");
   if (d->q_heads % d->kv_heads != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: q_heads % kv_heads != 0");
-  if (d->act_f32 && (2 * d->B <= 4 || !d->sample.embed.act_f32))
-    return dia_fail(DIA_E_ARG, "dia_engine_create: act_f32 needs more than 4 rows and an embedding that writes fp32 tiles too");
-  if (!d->act_f32 && d->sample.embed.act_f32) return dia_fail(DIA_E_ARG, "dia_engine_create: the embedding writes fp32 tiles but the engine reads planes");
   if (!d->x || !d->planes_x || !d->planes_a || !d->planes_h || !d->ssq || !d->qkv || !d->qc || !d->logits || !d->cos_t ||
       !d->sin_t || !d->text_len || !d->w_logits || !d->g_final || !d->attn_scratch || !d->attn_tickets)
     return dia_fail(DIA_E_ARG, "dia_engine_create: missing buffer");

@@ -75,18 +75,21 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
     for (int i = 0; i < AP; ++i)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        load_afrag3(p, aoff[mt] + (long)(kt0 + i) * 512, a0[i][mt][0], a0[i][mt][1], a0[i][mt][2]);
+#pragma unroll
+        for (int pl = 0; pl < DIA_NPLANES; ++pl)
+          a0[i][mt][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt0 + i) * 512);
     prefetch_epilogue<MT, NW * 64>(p, tid, mt0, m, n0, live, xpre, gpre, inv_s);
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        bf16x8 a3[DIA_NPLANES];
-        if (i < AP) { a3[0] = a0[i < AP ? i : 0][mt][0]; a3[1] = a0[i < AP ? i : 0][mt][1]; a3[2] = a0[i < AP ? i : 0][mt][2]; }
-        else load_afrag3(p, aoff[mt] + (long)(kt0 + i) * 512, a3[0], a3[1], a3[2]);
 #pragma unroll
-        for (int pl = 0; pl < DIA_NPLANES; ++pl)
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[pl], b[i], acc[mt], 0, 0, 0);
+        for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+          bf16x8 a;
+          if (i < AP) a = a0[i < AP ? i : 0][mt][pl];
+          else a = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt0 + i) * 512);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
+        }
       }
     }
   } else {
@@ -101,11 +104,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
         if (kt + i < kt1) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            bf16x8 a3[DIA_NPLANES];
-            load_afrag3(p, aoff[mt] + (long)(kt + i) * 512, a3[0], a3[1], a3[2]);
 #pragma unroll
-            for (int pl = 0; pl < DIA_NPLANES; ++pl)
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[pl], b[i], acc[mt], 0, 0, 0);
+            for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+              bf16x8 a = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt + i) * 512);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
+            }
           }
         }
       }
@@ -304,11 +307,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   // batch-8 step)
   if constexpr (MZ) {
     const int z = blockIdx.z;
-    p.A += (long)z * p.a_ktiles * 512 * (p.a_f32 ? 2 : 1);       // (bf16_raw pointer: an fp32 tile set is twice as wide)
+    p.A += (long)z * p.a_ktiles * 512;
     p.M = min(16, p.M - 16 * z);
     if (p.ssq_in) p.ssq_in += 16 * z;
     if (p.out) p.out += (long)16 * z * p.ldo;
-    if (p.P) p.P += (long)z * p.p_ktiles * 512 * (p.p_f32 ? 2 : 1);
+    if (p.P) p.P += (long)z * p.p_ktiles * 512;
     if (p.ssq_out) p.ssq_out += 16 * z;
     if (p.sk_scratch) { p.sk_scratch += (long)z * p.nstrips * gridDim.y * 256; p.sk_tickets += z * p.nstrips; }
   }
@@ -333,20 +336,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   // A fragments (rows >= M alias the last valid row: no extra L2 traffic, results never stored)
   const int alane = (lane & 48) | min(lane & 15, p.M - 1);
   bf16x8 a[KPW][DIA_NPLANES];
-  if (p.a_f32) {            // fp32 tiles: 32 bytes per fragment, every load issued before the first conversion
-    const float4* Af = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.A) + ((long)kt0 * 64 + alane) * 8);
-    float4 ax[KPW], ay[KPW];
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) { ax[i] = Af[(long)i * 128]; ay[i] = Af[(long)i * 128 + 1]; }
+  for (int i = 0; i < KPW; ++i)
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) split3x8(ax[i], ay[i], a[i][0], a[i][1], a[i][2]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < KPW; ++i)
-#pragma unroll
-      for (int pl = 0; pl < DIA_NPLANES; ++pl)
-        a[i][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)(kt0 + i) * 64 + alane) * 8);
-  }
+    for (int pl = 0; pl < DIA_NPLANES; ++pl)
+      a[i][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)(kt0 + i) * 64 + alane) * 8);
   // strip sums of squares: 8 threads per row
   const bool has_norm = p.ssq_in != nullptr;
   const int s_row = tid >> 3, s_part = tid & 7;
@@ -425,34 +419,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
             e = (g / (1.0f + expf(-g))) * u;
             emit = live && c16 < 8;
           }
-        }
-        if (p.p_f32) {                              // fp32 tiles: one value per thread, staged so that they leave as 16-byte stores
-          float* Pf = reinterpret_cast<float*>(p.P);
-          if (resid && p.cmap) {
-            if (emit) {
-              const int cc = p.cmap[strip * 16 + c16];
-              if (cc >= 0) Pf[plane_frag_off(r16, cc & ~7, p.p_ktiles) + (cc & 7)] = e;
-            }
-          } else {
-            float* stgf = reinterpret_cast<float*>(stg);            // [16][16] fp32 (1 KB of the 1.5 KB staging area)
-            if (r_thread) stgf[r16 * 16 + ecol] = e;
-            lds_barrier();
-            STAMP(4);
-            if (resid) {
-              if (tid < 64) {
-                const int mm = tid >> 2, q = tid & 3;
-                if (mm < p.M)
-                  *reinterpret_cast<float4*>(Pf + plane_frag_off(mm, strip * 16 + (q >> 1) * 8, p.p_ktiles) + (q & 1) * 4) =
-                      *reinterpret_cast<const float4*>(&stgf[mm * 16 + q * 4]);
-              }
-            } else if (tid < 32) {
-              const int mm = tid >> 1, q = tid & 1;
-              if (mm < p.M)
-                *reinterpret_cast<float4*>(Pf + plane_frag_off(mm, strip * 8, p.p_ktiles) + q * 4) =
-                    *reinterpret_cast<const float4*>(&stgf[mm * 16 + q * 4]);
-            }
-          }
-          return;
         }
         __bf16 ea, eb, ec;
         split3(e, ea, eb, ec);
@@ -1056,7 +1022,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   const int sk = a->sk > 1 ? a->sk : 1;
   if (sk > 1 && (!a->sk_scratch || !a->sk_tickets || a->KT % sk != 0)) return dia_fail(DIA_E_ARG, "dia_gemm: split-K needs sk_scratch, sk_tickets and KT % sk == 0");
   if (sk > 1 && !a->nw) { const int ktl = a->KT / sk; nw = (ktl % 16 == 0 && ktl / 16 <= 4) ? 16 : ((ktl % 8 == 0) ? 8 : 4); }
-  if (a->M <= 4 && fast_epi && !a->act_f32) {      // (k_gemv_small stages the three planes; fp32 tiles go to the 16-row kernel)
+  if (a->M <= 4 && fast_epi) {
     const int rs = a->M <= 2 ? 2 : 4;
     if (small_smem(nw, a->KT / sk, rs) <= 150 * 1024) {
       bool handled = false;
@@ -1085,7 +1051,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
     if (handled) return rc;
   }
 #ifdef DIA_EXPERIMENTS
-  if (mtiles == 2 && !a->act_f32) {       // earlier forms for 17..32 rows (k_gemm_blk32, k_gemm32, k_gemm32m), selected by tuning knobs
+  if (mtiles == 2) {       // earlier forms for 17..32 rows (k_gemm_blk32, k_gemm32, k_gemm32m), selected by tuning knobs
     bool handled = false;
     int rc = dia_exp_gemm_two_mtiles(a, stream, handled);
     if (handled) return rc;
@@ -1097,7 +1063,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   {
     const int blocks = ((mtiles + GT_MT - 1) / GT_MT) * ((a->nstrips + 15) / 16);
     const int min_blocks = dia_tune(DIA_TUNE_TILE_MIN_BLOCKS) >= 0 ? dia_tune(DIA_TUNE_TILE_MIN_BLOCKS) : 48;
-    if (mtiles >= 3 && a->KT % 8 == 0 && blocks >= min_blocks && !a->act_f32) {      // (the tiled kernel stages planes)
+    if (mtiles >= 3 && a->KT % 8 == 0 && blocks >= min_blocks) {
 #ifdef DIA_EXPERIMENTS
       const int v = dia_tune(DIA_TUNE_TILE_V);
       if (v >= 0 && v <= 2) return dia_exp_tile_variant(a, stream, v);
