@@ -188,6 +188,7 @@ def measure(w, cfg, *, batch, kv, steps, warmup, use_graph=True, seeds=None, dis
            "elapsed_s": elapsed, "ms_per_step": round(elapsed / steps * 1e3, 4), "device_ms_per_step": round(dev_ms / steps, 4),
            "frames_per_s": round(batch * steps / elapsed, 2), "rtf_per_utterance": round(steps / elapsed / FRAME_RATE, 3),
            "decode_weight_bytes": int(w.decode_weight_bytes()),
+           "activations": "fp32 tiles, planes split in registers (more than 4 rows)" if sess.act_f32 else "three bf16 planes (hi + mid + lo == fp32)",
            "step_roofline": {"bytes_per_step": int(step_bytes), "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
            "prefill": prefill}
@@ -300,7 +301,7 @@ def main():
         "rtf_aggregate": round(value / FRAME_RATE, 2),
         "prefill_s": m["prefill"]["host_s_first_call"], "prefill": m["prefill"], "weights_load_s": round(load_s, 2),
         "weights_bcast_s": round(bcast_s, 3),
-        "device_ms_per_step": m["device_ms_per_step"], "decode_weight_bytes": m["decode_weight_bytes"], "preheat_steps": args.preheat,
+        "device_ms_per_step": m["device_ms_per_step"], "decode_weight_bytes": m["decode_weight_bytes"], "activations": m["activations"], "preheat_steps": args.preheat,
         "step_roofline": m["step_roofline"],
     }
     if "kernels" in m:
@@ -339,7 +340,7 @@ def main():
 
         def brief(r, name):
             return {"workload": name, "frames_per_s": r["frames_per_s"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
-                    "rtf_per_utterance": r["rtf_per_utterance"], "decode_weight_bytes": r["decode_weight_bytes"],
+                    "rtf_per_utterance": r["rtf_per_utterance"], "decode_weight_bytes": r["decode_weight_bytes"], "activations": r["activations"],
                     "step_bytes": r["step_roofline"]["bytes_per_step"], "step_frac_of_hbm_peak": r["step_roofline"]["frac"],
                     "prefill_gpu_ms": round(r["prefill"]["gpu_s"] * 1e3, 2), "prefill_mfma_frac": r["prefill"]["mfma_frac"]}
 

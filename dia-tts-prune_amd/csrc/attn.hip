@@ -43,6 +43,7 @@ struct AttnK {
   const int* head_map;
   int v_blocked;
   int gpw;          // MFMA kernel: granules a wave takes before the keys are split over another workgroup
+  int act_f32;      // output as fp32 activation tiles instead of three bf16 planes
 };
 
 #ifdef DIA_DBG_STAMPS
@@ -158,11 +159,15 @@ __device__ __forceinline__ void attn_finish(const AttnK& p, const float* part, c
     for (int j = 0; j < 8; ++j) o[j] *= invl;
     const int hpos = p.head_map ? p.head_map[kvh * G + og] : kvh * G + og;   // compacted o_proj input
     const int col = hpos * HD + od0;
-    if (hpos >= 0) emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, qrow, col, o);
+    auto emit = [&](int row, const float* v8) {       // the o-projection's A operand: three planes, or fp32 tiles (common.hpp)
+      if (p.act_f32) emit_f32x8(reinterpret_cast<float*>(p.P), p.p_ktiles, row, col, v8);
+      else emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, row, col, v8);
+    };
+    if (hpos >= 0) emit(qrow, o);
     if (p.mode == DIA_ATTN_CROSS && hpos >= 0) {
       // the uncond row's cross-attention mask is all False -> SDPA returns 0
       const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, qrow - 1, col, z);
+      emit(qrow - 1, z);
     }
   }
   ASTAMP(6);
@@ -865,7 +870,7 @@ extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
   k.q = a->q; k.ldq = a->ldq; k.q_off = a->q_off; k.k_off = a->k_off; k.v_off = a->v_off;
   k.kc = a->kc; k.vc = a->vc; k.cur = a->cur; k.len = a->len; k.enc_len = a->enc_len;
   k.cos_t = a->cos_t; k.sin_t = a->sin_t;
-  k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles;
+  k.P = (bf16_raw*)a->P; k.p_plane_stride = a->p_plane_stride; k.p_ktiles = a->p_ktiles; k.act_f32 = a->act_f32;
   k.head_map = a->head_map; k.v_blocked = a->v_blocked;
   k.gpw = 1;
   { const int g = dia_tune(a->mode == DIA_ATTN_CROSS ? DIA_TUNE_ATTN_GPW_CROSS : DIA_TUNE_ATTN_GPW); if (g > 0) k.gpw = g; }

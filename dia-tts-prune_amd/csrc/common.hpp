@@ -63,6 +63,34 @@ __device__ __forceinline__ void emit_planes8(bf16_raw* P, long plane_stride, int
   *reinterpret_cast<bf16x8*>(P + 2 * plane_stride + off) = lo;
 }
 
+// ---- fp32 activation tiles ("act_f32"): the same [mtile][ktile][lane][8] fragment order as one plane, 4-byte elements
+// (4 bytes per value instead of the 6 of three planes).  The 5..128-row GEMM holds its A fragments in registers and every
+// workgroup pulls the whole activation matrix (16 rows x K): at batch 8 that image is 192 KB per workgroup against 64 KB of
+// weights, and it is what the head of each launch waits for.  The consumer splits each value into its three bf16 planes in
+// registers (hi + mid + lo == v exactly, as the producer used to), so the arithmetic is unchanged bit for bit.
+__device__ __forceinline__ void emit_f32x8(float* P, int ktiles, int m, int k0, const float* v) {
+  float* o = P + plane_frag_off(m, k0, ktiles);
+  *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void emit_f32x8_mapped(float* P, int ktiles, int m, int n0, const float* v, const int* cmap) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cmap[n0 + j];
+    if (c >= 0) P[plane_frag_off(m, c & ~7, ktiles) + (c & 7)] = v[j];
+  }
+}
+// 8 fp32 values -> the three bf16x8 MFMA fragments their planes would have held
+__device__ __forceinline__ void split3x8(const float4 x, const float4 y, bf16x8& h, bf16x8& mi, bf16x8& lo) {
+  const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 a, b, c;
+    split3(v[j], a, b, c);
+    h[j] = a; mi[j] = b; lo[j] = c;
+  }
+}
+
 // Workgroup barrier for LDS hand-offs that does NOT drain outstanding global loads: __syncthreads()
 // makes hipcc wait vmcnt(0), which would serialise the weight stream behind every barrier (guide §5
 // 'Pipelining across barriers').  LDS operations are waited for explicitly.

@@ -71,6 +71,12 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   const long xs = mt * xkt * 512, as = mt * akt * 512, hs = mt * hkt * 512;   // plane strides (elements)
   const int nqkv = (d.q_heads + 2 * d.kv_heads) * 128;
   int n = 0, rc;
+  // activation format per producer -> consumer edge (common.hpp): fp32 tiles from 5 rows on — except into a GEMM that runs the
+  // persistent 8-wave x 8-k-tile form at one m-tile (dense wi, the logits head): that form sits at the 256-VGPR limit and the
+  // in-register plane split spills (wi 16.9 -> 22.6 us, logits 11.4 -> 16.7 with fp32 input); it keeps reading planes
+  const int F = d.act_f32 ? 1 : 0;
+  auto persistent8 = [&](int kt, int ns) { return R <= 16 && kt == 64 && ns > 256; };
+  const int LG = (F && !persistent8(d.kt_logits, d.ns_logits)) ? 1 : 0;
   // 17..32 rows: every GEMM may split K inside dia_gemm (k_gemm32 / k_gemm32m) when it is handed the scratch
   const bool two_tiles = R > 16 && R <= 32 && d.sk_scratch && d.sk_tickets && d.sk_scratch_floats > 0;   // (k_gemm32 / k_gemm32m / blk32 only)
   auto lend_scratch = [&](dia_gemm_args& g) {
@@ -79,6 +85,8 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
 
   for (int l = 0; l < d.n_layer; ++l) {
     const dia_dec_layer& L = e->layers[l];
+    const int WI = (F && !persistent8(L.kt_wi, L.ns_wi)) ? 1 : 0;      // format of the edge co -> wi
+    const int XO = (l + 1 < d.n_layer) ? F : LG;                       // format of the edge wo -> next qkv / logits
     dia_gemm_args g = {};
     // q/k/v projection of the pre-SA-normed row (layers.py:541, 273-275)
     g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
@@ -86,6 +94,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
     g.out = d.qkv; g.ldo = nqkv; g.strip_map = L.smap_qkv;
     lend_scratch(g);
+  g.act_f32 = F;            // reads x as fp32 tiles
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     dia_attn_args a = {};
@@ -95,6 +104,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     a.head_map = L.hmap_self; a.v_blocked = d.v_blocked; a.rope_rows = d.T + 1;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
     a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
+    a.act_f32 = F;
     if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
 
     // o_proj + residual; emits the pre-CA-normed planes (layers.py:341-343, 555, 560)
@@ -104,6 +114,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_ca; g.cmap = L.cmap_ca;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     lend_scratch(g);
+  g.act_f32 = 3 * F;        // attention output in, x out: both fp32 tiles
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // cross-attention query (layers.py:273, 278)
@@ -113,6 +124,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
     g.out = d.qc; g.ldo = d.cq_heads * 128; g.strip_map = L.smap_cq;
     lend_scratch(g);
+  g.act_f32 = F;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     a = {};
@@ -121,6 +133,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     a.kc = L.k_cross; a.vc = L.v_cross; a.cur = d.sample.cur; a.len = d.text_len; a.head_map = L.hmap_cross; a.v_blocked = d.v_blocked;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
     a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
+    a.act_f32 = F;
     if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
 
     g = {};
@@ -129,6 +142,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_mlp; g.cmap = L.cmap_mlp;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     lend_scratch(g);
+  g.act_f32 = F | (WI << 1); // x out in the format wi reads
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // SwiGLU MLP (layers.py:95-104)
@@ -183,6 +197,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
       e->mlp_fused = 0;                      // not available for this model: do not try again
     }
     lend_scratch(gi);
+    gi.act_f32 = WI | (F << 1); g.act_f32 = F | (XO << 1);      // wi: x in, hidden out; wo: hidden in, x out
     if ((rc = dia_gemm(&gi, st))) return rc; mark(e, n++);
     rc = dia_gemm(&g, st);
     if (rc == DIA_E_ARG && g.sk > 1) {
@@ -200,6 +215,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
   g.out = d.logits; g.ldo = d.ld_logits;
   lend_scratch(g);
+  g.act_f32 = LG;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
   if (with_sampler) {
     if ((rc = dia_sample(&d.sample, st))) return rc; mark(e, n++);
@@ -214,6 +230,9 @@ extern "C" int dia_engine_create(const dia_engine_desc* d, void* stream, dia_eng
   if (d->D % 32 != 0 || d->F % 32 != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: D and F must be multiples of 32");
   if (d->rows_pad < 2 * d->B || d->rows_pad % 16 != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: rows_pad must be 16*ceil(2B/16)");
   if (d->q_heads % d->kv_heads != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: q_heads % kv_heads != 0");
+  if (d->act_f32 && (2 * d->B <= 4 || !d->sample.embed.act_f32))
+    return dia_fail(DIA_E_ARG, "dia_engine_create: act_f32 needs more than 4 rows and an embedding that writes fp32 tiles too");
+  if (!d->act_f32 && d->sample.embed.act_f32) return dia_fail(DIA_E_ARG, "dia_engine_create: the embedding writes fp32 tiles but the engine reads planes");
   if (!d->x || !d->planes_x || !d->planes_a || !d->planes_h || !d->ssq || !d->qkv || !d->qc || !d->logits || !d->cos_t ||
       !d->sin_t || !d->text_len || !d->w_logits || !d->g_final || !d->attn_scratch || !d->attn_tickets)
     return dia_fail(DIA_E_ARG, "dia_engine_create: missing buffer");

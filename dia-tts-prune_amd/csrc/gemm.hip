@@ -75,21 +75,18 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
     for (int i = 0; i < AP; ++i)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int pl = 0; pl < DIA_NPLANES; ++pl)
-          a0[i][mt][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt0 + i) * 512);
+        load_afrag3(p, aoff[mt] + (long)(kt0 + i) * 512, a0[i][mt][0], a0[i][mt][1], a0[i][mt][2]);
     prefetch_epilogue<MT, NW * 64>(p, tid, mt0, m, n0, live, xpre, gpre, inv_s);
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        bf16x8 a3[DIA_NPLANES];
+        if (i < AP) { a3[0] = a0[i < AP ? i : 0][mt][0]; a3[1] = a0[i < AP ? i : 0][mt][1]; a3[2] = a0[i < AP ? i : 0][mt][2]; }
+        else load_afrag3(p, aoff[mt] + (long)(kt0 + i) * 512, a3[0], a3[1], a3[2]);
 #pragma unroll
-        for (int pl = 0; pl < DIA_NPLANES; ++pl) {
-          bf16x8 a;
-          if (i < AP) a = a0[i < AP ? i : 0][mt][pl];
-          else a = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt0 + i) * 512);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
-        }
+        for (int pl = 0; pl < DIA_NPLANES; ++pl)
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[pl], b[i], acc[mt], 0, 0, 0);
       }
     }
   } else {
@@ -104,11 +101,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
         if (kt + i < kt1) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
+            bf16x8 a3[DIA_NPLANES];
+            load_afrag3(p, aoff[mt] + (long)(kt + i) * 512, a3[0], a3[1], a3[2]);
 #pragma unroll
-            for (int pl = 0; pl < DIA_NPLANES; ++pl) {
-              bf16x8 a = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + aoff[mt] + (long)(kt + i) * 512);
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc[mt], 0, 0, 0);
-            }
+            for (int pl = 0; pl < DIA_NPLANES; ++pl)
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[pl], b[i], acc[mt], 0, 0, 0);
           }
         }
       }
@@ -287,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
 #define DIA_Z_TEMPORAL 1
 #endif
 constexpr bool ZTEMPORAL = DIA_Z_TEMPORAL != 0;
-template <int NW, int KPW, bool MULTI, bool MZ = false>
+template <int NW, int KPW, bool MULTI, bool MZ = false, bool AF32 = false, bool PF32 = false>
 __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
                                                     int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
   // (leading arguments = fields of p, preloaded into SGPRs: see k_gemv_small)
@@ -307,11 +304,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   // batch-8 step)
   if constexpr (MZ) {
     const int z = blockIdx.z;
-    p.A += (long)z * p.a_ktiles * 512;
+    p.A += (long)z * p.a_ktiles * 512 * (AF32 ? 2 : 1);       // (bf16_raw pointer: an fp32 tile set is twice as wide)
     p.M = min(16, p.M - 16 * z);
     if (p.ssq_in) p.ssq_in += 16 * z;
     if (p.out) p.out += (long)16 * z * p.ldo;
-    if (p.P) p.P += (long)z * p.p_ktiles * 512;
+    if (p.P) p.P += (long)z * p.p_ktiles * 512 * (PF32 ? 2 : 1);
     if (p.ssq_out) p.ssq_out += 16 * z;
     if (p.sk_scratch) { p.sk_scratch += (long)z * p.nstrips * gridDim.y * 256; p.sk_tickets += z * p.nstrips; }
   }
@@ -336,11 +333,25 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   // A fragments (rows >= M alias the last valid row: no extra L2 traffic, results never stored)
   const int alane = (lane & 48) | min(lane & 15, p.M - 1);
   bf16x8 a[KPW][DIA_NPLANES];
+  if constexpr (AF32) {     // fp32 tiles (compile-time: a second operand path behind a branch would end the basic block in which
+    // all loads of the wave are issued).  32 bytes per fragment; the raw values land in the registers of planes 0 and 1 of their
+    // own fragment and are split in place — no second register set beside the 12 * KPW VGPRs of `a`
+    const float4* Af = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.A) + ((long)kt0 * 64 + alane) * 8);
 #pragma unroll
-  for (int i = 0; i < KPW; ++i)
+    for (int i = 0; i < KPW; ++i) {
+      a[i][0] = __builtin_bit_cast(bf16x8, Af[(long)i * 128]);
+      a[i][1] = __builtin_bit_cast(bf16x8, Af[(long)i * 128 + 1]);
+    }
 #pragma unroll
-    for (int pl = 0; pl < DIA_NPLANES; ++pl)
-      a[i][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)(kt0 + i) * 64 + alane) * 8);
+    for (int i = 0; i < KPW; ++i)
+      split3x8(__builtin_bit_cast(float4, a[i][0]), __builtin_bit_cast(float4, a[i][1]), a[i][0], a[i][1], a[i][2]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl)
+        a[i][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)(kt0 + i) * 64 + alane) * 8);
+  }
   // strip sums of squares: 8 threads per row
   const bool has_norm = p.ssq_in != nullptr;
   const int s_row = tid >> 3, s_part = tid & 7;
@@ -420,6 +431,35 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
             emit = live && c16 < 8;
           }
         }
+        if constexpr (PF32) {                       // fp32 tiles: one value per thread, staged so that they leave as 16-byte stores
+          float* Pf = reinterpret_cast<float*>(p.P);
+          if (resid && p.cmap) {
+            if (emit) {
+              const int cc = p.cmap[strip * 16 + c16];
+              if (cc >= 0) Pf[plane_frag_off(r16, cc & ~7, p.p_ktiles) + (cc & 7)] = e;
+            }
+          } else {
+            float* stgf = reinterpret_cast<float*>(stg);            // [16][16] fp32 (1 KB of the 1.5 KB staging area)
+            if (r_thread) stgf[r16 * 16 + ecol] = e;
+            lds_barrier();
+            STAMP(4);
+            if (resid) {
+              if (tid < 64) {
+                const int mm = tid >> 2, q = tid & 3;
+                if (mm < p.M)
+                  *reinterpret_cast<float4*>(Pf + plane_frag_off(mm, strip * 16 + (q >> 1) * 8, p.p_ktiles) + (q & 1) * 4) =
+                      *reinterpret_cast<const float4*>(&stgf[mm * 16 + q * 4]);
+              }
+            } else if (tid < 32) {
+              const int mm = tid >> 1, q = tid & 1;
+              if (mm < p.M)
+                *reinterpret_cast<float4*>(Pf + plane_frag_off(mm, strip * 8, p.p_ktiles) + q * 4) =
+                    *reinterpret_cast<const float4*>(&stgf[mm * 16 + q * 4]);
+            }
+          }
+          return;
+        }
+        if constexpr (PF32) return;                 // (not reached: keeps the planes code below out of the fp32 instantiations)
         __bf16 ea, eb, ec;
         split3(e, ea, eb, ec);
         if (resid && p.cmap) {                      // compacted consumer: scattered two-byte stores
@@ -774,7 +814,7 @@ int launch_tile(const GemmK& k, hipStream_t st) {
   return launch_tile_ws<2, 2, 4>(k, st);
 }
 
-template <int NW, int KPW>
+template <int NW, int KPW, bool AF32 = false, bool PF32 = false>
 int launch_g16(const GemmK& k, hipStream_t st) {
   const size_t smem = sizeof(f32x4) * 2 * NW * 64 + 1536 + sizeof(float) * (2 * 16 * 17 + 16);
   const int sk = k.KT / (NW * KPW);
@@ -794,13 +834,13 @@ int launch_g16(const GemmK& k, hipStream_t st) {
     if (spw > 1) {      // persistent multi-strip form, with or without split-K: A fragments loaded once per workgroup
       int gx = (k.nstrips + spw - 1) / spw;
       if (mz >= 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
-      if (mz > 1) launch_small_kernel<k_gemm16<NW, KPW, true, true>>(dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
-      else launch_small_kernel<k_gemm16<NW, KPW, true>>(dim3(gx, sk), dim3(NW * 64), smem, st, k);
+      if (mz > 1) launch_small_kernel<k_gemm16<NW, KPW, true, true, AF32, PF32>>(dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
+      else launch_small_kernel<k_gemm16<NW, KPW, true, false, AF32, PF32>>(dim3(gx, sk), dim3(NW * 64), smem, st, k);
       return dia_check_launch("k_gemm16");
     }
   }
-  if (mz > 1) launch_small_kernel<k_gemm16<NW, KPW, false, true>>(dim3(k.nstrips, sk, mz), dim3(NW * 64), smem, st, k);
-  else launch_small_kernel<k_gemm16<NW, KPW, false>>(dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
+  if (mz > 1) launch_small_kernel<k_gemm16<NW, KPW, false, true, AF32, PF32>>(dim3(k.nstrips, sk, mz), dim3(NW * 64), smem, st, k);
+  else launch_small_kernel<k_gemm16<NW, KPW, false, false, AF32, PF32>>(dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
   return dia_check_launch("k_gemm16");
 }
 
@@ -808,6 +848,25 @@ int launch_g16(const GemmK& k, hipStream_t st) {
 int launch_g16_any(const GemmK& k, int nw, int sk, hipStream_t st, bool& handled) {
   handled = true;
   const int kpw = (k.KT % (nw * sk) == 0) ? k.KT / (nw * sk) : 0;
+  if (k.a_f32 || k.p_f32) {      // fp32 activation tiles on either side: the 8-wave forms (every decode shape from 5 rows on)
+    const bool emits = k.epi == DIA_EPI_RESID_EMIT || k.epi == DIA_EPI_SWIGLU_EMIT;
+    const bool pf = emits && k.p_f32;
+    if (nw == 8 && k.a_f32 && pf == emits) {           // fp32 in, fp32 out (or nothing emitted)
+      if (kpw == 1) return launch_g16<8, 1, true, true>(k, st);
+      if (kpw == 2) return launch_g16<8, 2, true, true>(k, st);
+      if (kpw == 3) return launch_g16<8, 3, true, true>(k, st);
+      if (kpw == 4) return launch_g16<8, 4, true, true>(k, st);
+      if (kpw == 5) return launch_g16<8, 5, true, true>(k, st);
+      if (kpw == 6) return launch_g16<8, 6, true, true>(k, st);
+      if (kpw == 7) return launch_g16<8, 7, true, true>(k, st);
+      if (kpw == 8) return launch_g16<8, 8, true, true>(k, st);
+    }
+    // mixed formats exist where the step needs them: around the persistent 8 x 8 forms, which stay on planes (engine.hip)
+    if (nw == 8 && kpw == 8 && k.a_f32 && emits && !pf) return launch_g16<8, 8, true, false>(k, st);
+    if (nw == 8 && kpw == 8 && !k.a_f32 && pf) return launch_g16<8, 8, false, true>(k, st);
+    handled = false;
+    return DIA_OK;
+  }
   if (nw == 16) {
     if (kpw == 1) return launch_g16<16, 1>(k, st);
     if (kpw == 2) return launch_g16<16, 2>(k, st);
@@ -1022,7 +1081,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   const int sk = a->sk > 1 ? a->sk : 1;
   if (sk > 1 && (!a->sk_scratch || !a->sk_tickets || a->KT % sk != 0)) return dia_fail(DIA_E_ARG, "dia_gemm: split-K needs sk_scratch, sk_tickets and KT % sk == 0");
   if (sk > 1 && !a->nw) { const int ktl = a->KT / sk; nw = (ktl % 16 == 0 && ktl / 16 <= 4) ? 16 : ((ktl % 8 == 0) ? 8 : 4); }
-  if (a->M <= 4 && fast_epi) {
+  if (a->M <= 4 && fast_epi && !a->act_f32) {      // (k_gemv_small stages the three planes; fp32 tiles go to the 16-row kernel)
     const int rs = a->M <= 2 ? 2 : 4;
     if (small_smem(nw, a->KT / sk, rs) <= 150 * 1024) {
       bool handled = false;
@@ -1051,7 +1110,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
     if (handled) return rc;
   }
 #ifdef DIA_EXPERIMENTS
-  if (mtiles == 2) {       // earlier forms for 17..32 rows (k_gemm_blk32, k_gemm32, k_gemm32m), selected by tuning knobs
+  if (mtiles == 2 && !a->act_f32) {       // earlier forms for 17..32 rows (k_gemm_blk32, k_gemm32, k_gemm32m), selected by tuning knobs
     bool handled = false;
     int rc = dia_exp_gemm_two_mtiles(a, stream, handled);
     if (handled) return rc;
@@ -1063,7 +1122,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   {
     const int blocks = ((mtiles + GT_MT - 1) / GT_MT) * ((a->nstrips + 15) / 16);
     const int min_blocks = dia_tune(DIA_TUNE_TILE_MIN_BLOCKS) >= 0 ? dia_tune(DIA_TUNE_TILE_MIN_BLOCKS) : 48;
-    if (mtiles >= 3 && a->KT % 8 == 0 && blocks >= min_blocks) {
+    if (mtiles >= 3 && a->KT % 8 == 0 && blocks >= min_blocks && !a->act_f32) {      // (the tiled kernel stages planes)
 #ifdef DIA_EXPERIMENTS
       const int v = dia_tune(DIA_TUNE_TILE_V);
       if (v >= 0 && v <= 2) return dia_exp_tile_variant(a, stream, v);

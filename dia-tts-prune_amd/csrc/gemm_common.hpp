@@ -50,7 +50,31 @@ struct GemmK {
   const int* row_b; const int* seg_off;   // CROSSKV over a packed batch
   const unsigned char* sp_blocks; const unsigned int* sp_toff;   // zero-skipping weight stream (k_gemv_sparse)
   int mz;                                  // host side only: m-tiles a k_gemm16 launch covers through gridDim.z (0/1 = one)
+  int a_f32, p_f32;                        // A / P are fp32 activation tiles (common.hpp) instead of three bf16 planes
 };
+
+// the three plane fragments of the A operand at element offset `off` inside a plane / an fp32 tile set
+__device__ __forceinline__ void load_afrag3(const GemmK& p, long off, bf16x8& a0, bf16x8& a1, bf16x8& a2) {
+  if (p.a_f32) {
+    const float4* s = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.A) + off);
+    split3x8(s[0], s[1], a0, a1, a2);
+  } else {
+    a0 = *reinterpret_cast<const bf16x8*>(p.A + off);
+    a1 = *reinterpret_cast<const bf16x8*>(p.A + p.a_plane_stride + off);
+    a2 = *reinterpret_cast<const bf16x8*>(p.A + 2 * p.a_plane_stride + off);
+  }
+}
+// 8 consecutive-column activations of row m leave in the consumer's format
+__device__ __forceinline__ void emit_act8(const GemmK& p, int m, int n0, const float* v, const int* cmap) {
+  if (p.p_f32) {
+    float* Pf = reinterpret_cast<float*>(p.P);
+    if (cmap) emit_f32x8_mapped(Pf, p.p_ktiles, m, n0, v, cmap);
+    else emit_f32x8(Pf, p.p_ktiles, m, n0, v);
+  } else {
+    if (cmap) emit_planes8_mapped(p.P, p.p_plane_stride, p.p_ktiles, m, n0, v, cmap);
+    else emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, m, n0, v);
+  }
+}
 
 template <auto Kern>
 void launch_small_kernel(dim3 grid, dim3 block, size_t smem, hipStream_t st, const GemmK& k) {
@@ -120,8 +144,7 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
       for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = mul_rn(v[j], gpre[j]);
-      if (p.cmap) emit_planes8_mapped(p.P, p.p_plane_stride, p.p_ktiles, m, n0, v, p.cmap);
-      else emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, m, n0, v);
+      emit_act8(p, m, n0, v, p.cmap);
     }
     float other = __shfl_xor(ss, 1, 64);
     if (half == 0 && live) p.ssq_out[(long)strip * p.ssq_ld + m] = ss + other;
@@ -133,7 +156,7 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
       float g = trow[j] * inv, u = trow[8 + j] * inv;
       v[j] = (g / (1.0f + expf(-g))) * u;
     }
-    emit_planes8(p.P, p.p_plane_stride, p.p_ktiles, m, strip * 8, v);
+    emit_act8(p, m, strip * 8, v, nullptr);
   } else {  // DIA_EPI_CROSSKV: strips [0, heads*8) hold K as RoPE pairs (d, d+64), the rest hold V
     if (!live) return;
     if (p.strip_map) strip = p.strip_map[strip];                  // compacted cross K/V: original strip index
@@ -320,6 +343,7 @@ inline int fill_gemmk(const dia_gemm_args* a, GemmK& k) {
   k.row_b = a->row_b; k.seg_off = a->seg_off;
   k.sp_blocks = (const unsigned char*)a->sp_blocks; k.sp_toff = (const unsigned int*)a->sp_toff;
   k.mz = 0;
+  k.a_f32 = a->act_f32 & 1; k.p_f32 = (a->act_f32 >> 1) & 1;
   return DIA_OK;
 }
 

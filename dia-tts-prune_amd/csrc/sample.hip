@@ -31,6 +31,7 @@ struct EmbedK {
   const float* emb; const float* g; float* x;
   bf16_raw* P; long p_plane_stride; int p_ktiles; int ssq_ld; float* ssq;
   const int* cmap;
+  int act_f32;
 };
 
 struct SampleK {
@@ -83,7 +84,10 @@ __device__ __forceinline__ void embed_rows(const EmbedK& e, int b, const int* to
       float* xo = e.x + (long)m * e.D + d0;
       *reinterpret_cast<float4*>(xo) = float4{v[0], v[1], v[2], v[3]};
       *reinterpret_cast<float4*>(xo + 4) = float4{v[4], v[5], v[6], v[7]};
-      if (e.cmap) emit_planes8_mapped(e.P, e.p_plane_stride, e.p_ktiles, m, d0, vg, e.cmap);
+      if (e.act_f32) {
+        if (e.cmap) emit_f32x8_mapped(reinterpret_cast<float*>(e.P), e.p_ktiles, m, d0, vg, e.cmap);
+        else emit_f32x8(reinterpret_cast<float*>(e.P), e.p_ktiles, m, d0, vg);
+      } else if (e.cmap) emit_planes8_mapped(e.P, e.p_plane_stride, e.p_ktiles, m, d0, vg, e.cmap);
       else emit_planes8(e.P, e.p_plane_stride, e.p_ktiles, m, d0, vg);
       if (((d0 >> 3) & 1) == 0) e.ssq[(long)(d0 >> 4) * e.ssq_ld + m] = ss + other;
     }
@@ -532,7 +536,7 @@ static int fill_embed(const dia_embed_args* a, EmbedK& e) {
   if (a->p_plane_stride % 8 != 0 || a->p_ktiles * 32 < a->D) return dia_fail(DIA_E_ARG, "embed: plane layout too narrow");
   e.tokens = a->tokens; e.cur = a->cur; e.B = a->B; e.T = a->T; e.C = a->C; e.V = a->V; e.D = a->D;
   e.emb = a->emb; e.g = a->g; e.x = a->x; e.P = (bf16_raw*)a->P; e.p_plane_stride = a->p_plane_stride;
-  e.p_ktiles = a->p_ktiles; e.ssq_ld = a->ssq_ld; e.ssq = a->ssq; e.cmap = a->cmap;
+  e.p_ktiles = a->p_ktiles; e.ssq_ld = a->ssq_ld; e.ssq = a->ssq; e.cmap = a->cmap; e.act_f32 = a->act_f32;
   return DIA_OK;
 }
 

@@ -14,7 +14,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIA_HIP_LIB") or os.path.join(_HERE, "libdia_hip.so")   # override: experiments only
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 KV_F32, KV_BF16 = 0, 1
 EPI_SCALE_STORE, EPI_RESID_EMIT, EPI_SWIGLU_EMIT, EPI_CROSSKV = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
@@ -44,6 +44,7 @@ class GemmArgs(C.Structure):
         ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p), ("sk", C.c_int32), ("kv_vblocked", C.c_int32),
         ("row_b", C.c_void_p), ("seg_off", C.c_void_p), ("sk_scratch_floats", C.c_int64),
         ("sp_blocks", C.c_void_p), ("sp_toff", C.c_void_p),
+        ("act_f32", C.c_int32), ("_pad_act", C.c_int32),
     ]
 
 
@@ -56,7 +57,7 @@ class AttnArgs(C.Structure):
         ("enc_len", C.c_int32), ("rope_rows", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("_pad1", C.c_int32),
         ("scratch", C.c_void_p), ("tickets", C.c_void_p), ("head_map", C.c_void_p),
-        ("v_blocked", C.c_int32), ("_pad2", C.c_int32),
+        ("v_blocked", C.c_int32), ("act_f32", C.c_int32),
     ]
 
 
@@ -87,7 +88,7 @@ class DecPrefillArgs(C.Structure):
 class EmbedArgs(C.Structure):
     _fields_ = [
         ("tokens", C.c_void_p), ("cur", C.c_void_p),
-        ("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("V", C.c_int32), ("D", C.c_int32), ("_pad0", C.c_int32),
+        ("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("V", C.c_int32), ("D", C.c_int32), ("act_f32", C.c_int32),
         ("emb", C.c_void_p), ("g", C.c_void_p), ("x", C.c_void_p), ("P", C.c_void_p),
         ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("ssq_ld", C.c_int32), ("ssq", C.c_void_p),
         ("cmap", C.c_void_p),
@@ -134,6 +135,7 @@ class EngineDesc(C.Structure):
         ("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("text_len", C.c_void_p),
         ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p),
         ("attn_scratch", C.c_void_p), ("attn_tickets", C.c_void_p), ("sk_scratch_floats", C.c_int64), ("mlp_barrier", C.c_void_p),
+        ("act_f32", C.c_int32), ("_pad_act", C.c_int32),
         ("sample", SampleArgs),
     ]
 

@@ -295,6 +295,11 @@ class DecodeSession:
         mt = self.rows_pad // 16
         self.xkt, self.akt, self.hkt = self.D // 32, max(d.gqa_query_heads, d.cross_query_heads) * HEAD_DIM // 32, self.F // 32
         self.x = z(self.rows_pad, self.D)
+        # activations between the kernels of a step: three bf16 planes (hi + mid + lo == fp32) up to 4 rows, where the GEMV stages
+        # them through LDS; from 5 rows on fp32 tiles in the same buffers (4 instead of 6 bytes per value: every workgroup of
+        # the 16-row GEMM pulls the whole activation matrix, 192 KB at batch 8, and splits the planes in registers — same
+        # arithmetic).  Tuning knob act_f32=0 keeps the planes.
+        self.act_f32 = int(self.R > 4 and hb.get_tuning("act_f32") != 0)
         self.planes_x = z(3, mt, self.xkt, 64, 8, dt=torch.bfloat16)
         self.planes_a = z(3, mt, self.akt, 64, 8, dt=torch.bfloat16)
         self.planes_h = z(3, mt, self.hkt, 64, 8, dt=torch.bfloat16)
@@ -403,6 +408,7 @@ class DecodeSession:
         e.P, e.p_plane_stride, e.p_ktiles = hb.ptr(self.planes_x), self.planes_x[0].numel(), self.xkt
         e.ssq_ld, e.ssq = self.rows_pad, hb.ptr(self.ssq)
         e.cmap = hb.ptr(self.w.cmap_first)
+        e.act_f32 = self.act_f32
         return e
 
     def _sample_args(self) -> hb.SampleArgs:
@@ -453,6 +459,7 @@ class DecodeSession:
         ed.sk_scratch, ed.sk_tickets = hb.ptr(self.sk_scratch), hb.ptr(self.sk_tickets)
         ed.sk_scratch_floats = self.sk_scratch.numel()
         ed.mlp_barrier = hb.ptr(self.mlp_barrier)
+        ed.act_f32 = self.act_f32
         ed.sample = self._sample_args()
         self._desc = ed
         hb.check(hb.lib().dia_engine_create(C.byref(ed), C.c_void_p(self.stream.cuda_stream), C.byref(self._engine)),
@@ -752,6 +759,7 @@ class DecodeSession:
             g.ssq_in, g.ssq_in_n, g.ssq_ld = hb.ptr(self.ssq), self.D // 16, self.rows_pad
             g.inv_d, g.eps = 1.0 / self.D, float(self.cfg.model.normalization_layer_epsilon)
             g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(self.planes_h), self.planes_h[0].numel(), self.hkt
+            g.act_f32 = 3 * self.act_f32             # as in the step
             args.append(g)
         for g in args:                                    # warm
             hb.check(L.dia_gemm(C.byref(g), st), "dia_gemm(wi)")

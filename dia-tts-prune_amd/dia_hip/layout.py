@@ -69,6 +69,23 @@ def unpack_planes(p: torch.Tensor, M: int, K: int) -> torch.Tensor:
     return x[:M, :K].contiguous()
 
 
+def pack_f32_tiles(x: torch.Tensor, ktiles: int | None = None, mtiles: int | None = None) -> torch.Tensor:
+    """fp32 [M, K] -> fp32 activation tiles [mtiles, ktiles, 64, 8]: the fragment order of one plane with 4-byte elements
+    (dia_gemm_args.act_f32; the 5..128-row kernels split the planes in registers)."""
+    M, K = x.shape
+    mt = mtiles if mtiles is not None else _ceil(M, 16) // 16
+    kt = ktiles if ktiles is not None else _ceil(K, 32) // 32
+    xp = torch.zeros(mt * 16, kt * 32, dtype=torch.float32, device=x.device)
+    xp[:M, :K] = x
+    return xp.reshape(mt, 16, kt, 4, 8).permute(0, 2, 3, 1, 4).reshape(mt, kt, 64, 8).contiguous()
+
+
+def unpack_f32_tiles(t: torch.Tensor, M: int, K: int) -> torch.Tensor:
+    """inverse of pack_f32_tiles"""
+    mt, kt = t.shape[:2]
+    return t.reshape(mt, kt, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(mt * 16, kt * 32)[:M, :K].contiguous()
+
+
 def interleave_gate_up(wi: torch.Tensor) -> torch.Tensor:
     """wi_fused kernel [D, 2, F] (layers.py:77-82) -> [D, 2F] where every 16-column strip holds
     8 gate columns followed by the 8 matching up columns."""

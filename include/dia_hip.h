@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DIA_ABI_VERSION 3
+#define DIA_ABI_VERSION 4
 
 #define DIA_OK 0
 #define DIA_E_ARG (-1)     /* bad argument / unsupported shape */
@@ -126,6 +126,14 @@ typedef struct {
    * M <= 4, KT in {16, 32, 64}, no split-K; results are bit-identical to the dense tiles of the same matrix. */
   const void* sp_blocks;
   const uint32_t* sp_toff;
+  /* fp32 ACTIVATION TILES: bit 0 = A is, bit 1 = P receives the fragment order of one plane ([mtile][ktile][lane][8]) with 4-byte
+   * elements — 4 bytes per value instead of the 6 of three planes (a_plane_stride / p_plane_stride unused; a buffer sized for three
+   * planes holds them).  The 5..128-row kernel is instantiated per format and splits each value into its planes in registers: same
+   * arithmetic bit for bit, a third less activation traffic per workgroup.  8-wave forms; mixed formats (one bit set) only where
+   * K / 32 / sk == 64; anything else runs the generic kernel.  Not available in the M <= 4 kernel (dia_gemm then takes the 16-row
+   * one) nor in the tiled prefill kernel. */
+  int32_t act_f32;
+  int32_t _pad_act;
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
@@ -182,7 +190,7 @@ typedef struct {
   /* 1: bf16 caches with V stored blocked as [key/32][128 dims][32 keys] (K stays [key][128]) -> the MFMA
    * attention kernel; 0: V stored [key][128] -> the VALU kernel (required for fp32 caches and ENC) */
   int32_t v_blocked;
-  int32_t _pad2;
+  int32_t act_f32;          /* 1: P receives fp32 activation tiles (dia_gemm_args.act_f32) instead of three planes */
 } dia_attn_args;
 int dia_attn(const dia_attn_args* a, void* stream);
 int dia_attn_scratch_floats(int n_rows, int n_kv_heads, int kv_cap);
@@ -257,7 +265,7 @@ typedef struct {
   const int32_t* tokens;    /* [B][T][C] */
   const int32_t* cur;       /* [B] */
   int32_t B, T, C, V, D;
-  int32_t _pad0;
+  int32_t act_f32;          /* 1: P receives fp32 activation tiles (dia_gemm_args.act_f32) instead of three planes */
   const float* emb;         /* [C][V][D] fp32 */
   const float* g;           /* first pre_sa_norm weight */
   float* x;                 /* [rows][D] */
@@ -360,6 +368,9 @@ typedef struct {
   int32_t* attn_tickets;    /* max(R*kv_heads, B*cq_heads) int32, zeroed by the caller once */
   int64_t sk_scratch_floats;/* capacity of sk_scratch in floats (0 = the minimum above) */
   int32_t* mlp_barrier;     /* 2 int32 zeroed by the caller once: dia_mlp_fused's barrier words (NULL = never fuse) */
+  int32_t act_f32;          /* 1: planes_x / planes_a / planes_h carry fp32 activation tiles (dia_gemm_args.act_f32); needs
+                             * more than 4 rows (B >= 3) and sample.embed.act_f32 == 1 */
+  int32_t _pad_act;
   dia_sample_args sample;   /* sampler + FSM + embedding parameters */
 } dia_engine_desc;
 

@@ -16,6 +16,7 @@ ap.add_argument("--K", type=int, default=0, help="with --N: a custom RESID_EMIT 
 ap.add_argument("--N", type=int, default=0)
 ap.add_argument("--graph", type=int, default=0, help="capture 8 x 18 launches into a graph and replay it (per-launch time without the eager launch rate limit)")
 ap.add_argument("--lend", type=int, default=0, help="lend split-K scratch (floats per strip and k-tile/8) so dia_gemm may pick k_gemm_blk32 at 17..32 rows")
+ap.add_argument("--f32", type=int, default=0, help="1: A and P as fp32 activation tiles (act_f32)")
 ap.add_argument("--sparse", type=float, default=0.0, help="fraction of zero weights -> zero-skipping stream")
 a = ap.parse_args()
 d = torch.device("cuda:0")
@@ -37,13 +38,15 @@ if a.sparse > 0:
     print("stream bytes", SP[0][0].numel(), "dense", Ws[0].numel() * 2)
 x = torch.randn(M, K, device=d)
 A = lay.pack_planes(x)
+if a.f32:          # fp32 tiles live in a buffer sized for three planes, like in the engine
+    A.view(torch.float32).reshape(-1)[: A[0].numel()] = lay.pack_f32_tiles(x).reshape(-1)
 ssq = torch.ones(K // 16, mpad, device=d)
 out = torch.zeros(mpad, max(N, 16), device=d)
 P = torch.zeros(3, mpad // 16, max(N // 32, 1) if epi != hb.EPI_SWIGLU_EMIT else N // 64, 64, 8, dtype=torch.bfloat16, device=d)
 ssq_out = torch.zeros(N // 16, mpad, device=d)
 gn = torch.ones(N, device=d)
 L = hb.lib()
-hb.get_tuning("gemm_spw")         # (reads DIA_TUNE: nothing else in this script initialises the tuning table)
+hb.get_tuning("act_f32")          # (reads DIA_TUNE: nothing else in this script initialises the tuning table)
 st = torch.cuda.Stream()
 skscr = torch.zeros(2 * (N // 16) * 8 * 256, device=d); sktk = torch.zeros(2 * (N // 16), dtype=torch.int32, device=d)
 lendscr = torch.zeros((N // 16) * (K // 256) * 512, device=d) if a.lend else None
@@ -51,6 +54,7 @@ def launch(W):
     g = hb.GemmArgs()
     g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
     g.W, g.KT, g.nstrips, g.epi, g.nw = hb.ptr(W), K // 32, N // 16, epi, a.nw
+    g.act_f32 = a.f32
     if SP is not None:
         i = next(j for j, x_ in enumerate(Ws) if x_ is W)
         g.W, g.sp_blocks, g.sp_toff = None, hb.ptr(SP[i][0]), hb.ptr(SP[i][1])

@@ -866,3 +866,132 @@ def test_padded_o_rows_ignore_stale_planes(M):
         outs.append((x, P.clone(), ssq))
     assert torch.isfinite(outs[1][0]).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp32 activation tiles (dia_gemm_args.act_f32): the 5..128-row kernels read / write the activations between the
+# kernels of a step as 4-byte values in the fragment order of one plane and split the three bf16 planes in
+# registers.  The arithmetic is the planes path's, so every output must be IDENTICAL bit for bit.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N,epi,sk,mapped", [
+    (5, 2048, 2048, "resid", 0, False), (16, 2048, 2048, "resid", 0, True), (16, 8192, 2048, "resid", 4, False),
+    (16, 4096, 2048, "resid", 2, True), (40, 2048, 2048, "resid", 0, True), (128, 8192, 2048, "resid", 4, False),
+    (16, 2048, 16384, "swiglu", 0, False), (24, 1024, 4096, "swiglu", 0, False),
+    (16, 2048, 3072, "store", 0, False), (7, 1792, 1024, "store", 0, False), (64, 2048, 9264, "store", 0, False),
+    (16, 96, 80, "resid_generic", 0, False)])
+@pytest.mark.parametrize("fmt", [3, 1, 2])
+def test_act_f32_tiles_equal_planes_bitwise(M, K, N, epi, sk, mapped, fmt):
+    """fmt: dia_gemm_args.act_f32 — bit 0 the A operand, bit 1 the emitted activations are fp32 tiles (3 = both; the mixed
+    forms exist for the 8 x 8 shapes the decode step mixes: around the persistent wi / logits launches, which keep planes)"""
+    if fmt != 3 and not (K // 32 // max(sk, 1) == 64 and epi in ("resid", "swiglu") and M <= 16):
+        pytest.skip("mixed formats are instantiated for the 8-wave x 8-k-tile forms only")
+    d = dev()
+    torch.manual_seed(M + K + N)
+    x_in = torch.randn(M, K, device=d) * 3
+    Npad = (N + 15) // 16 * 16
+    W = torch.zeros(K, Npad, device=d)
+    W[:, :N] = bf16r(torch.randn(K, N, device=d) * 0.03)
+    Wt, kt, ns = lay.tile_weight(W)
+    mpad = (M + 15) // 16 * 16
+    mt = mpad // 16
+    resid = epi.startswith("resid")
+    D_out = Npad if resid else (Npad // 2 if epi == "swiglu" else 0)
+    pkt = (D_out + 31) // 32 if D_out else 1
+    keep = torch.rand(max(Npad, 1), device=d) < 0.6
+    cmap = torch.where(keep, torch.cumsum(keep.int(), 0) - 1, torch.full((Npad,), -1, device=d, dtype=torch.int64)).to(torch.int32)
+    gn = bf16r(1.0 + 0.1 * torch.randn(Npad, device=d))
+    ssq_in = strip_ssq(x_in, mpad) if not resid else None
+    x0 = torch.randn(mpad, Npad, device=d)
+    res = []
+    for f32 in (0, 1):
+        A = lay.pack_planes(x_in)
+        af, pf = bool(f32 and fmt & 1), bool(f32 and fmt & 2)
+        if af:
+            A.view(torch.float32).reshape(-1)[: A[0].numel()] = lay.pack_f32_tiles(x_in).reshape(-1)
+        g = hb.GemmArgs()
+        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+        g.W, g.KT, g.nstrips = hb.ptr(Wt), kt, ns
+        g.epi = {"resid": hb.EPI_RESID_EMIT, "resid_generic": hb.EPI_RESID_EMIT, "swiglu": hb.EPI_SWIGLU_EMIT, "store": hb.EPI_SCALE_STORE}[epi]
+        g.act_f32 = fmt * f32
+        out = x0.clone() if resid else torch.zeros(mpad, Npad, device=d)
+        P = torch.full((3, mt, pkt, 64, 8), 7.0, dtype=torch.bfloat16, device=d)       # (7.0 in bf16 = 0x40E0: as fp32 pairs a finite sentinel too)
+        ssq_o = torch.zeros(ns, mpad, device=d)
+        g.ssq_ld = mpad
+        if ssq_in is not None:
+            g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq_in), ssq_in.shape[0], 1.0 / K, 1e-5
+        if epi != "swiglu":
+            g.out, g.ldo = hb.ptr(out), Npad
+        if resid:
+            g.gnext, g.ssq_out = hb.ptr(gn), hb.ptr(ssq_o)
+            if mapped:
+                g.cmap = hb.ptr(cmap)
+        if D_out:
+            g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), pkt
+        if sk:
+            scr = torch.zeros(mt * ns * sk * 256, device=d)
+            tk = torch.zeros(mt * ns, dtype=torch.int32, device=d)
+            g.sk_scratch, g.sk_tickets, g.sk, g.sk_scratch_floats = hb.ptr(scr), hb.ptr(tk), sk, scr.numel()
+        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+        torch.cuda.synchronize()
+        if D_out:
+            if pf:
+                emitted = lay.unpack_f32_tiles(P.view(torch.float32).reshape(-1)[: mt * pkt * 512].reshape(mt, pkt, 64, 8), mpad, pkt * 32)
+            else:
+                emitted = lay.unpack_planes(P, mpad, pkt * 32)
+            nlive = int(keep[:Npad].sum()) if (resid and mapped) else D_out
+            emitted = emitted[:M, :nlive].clone()
+        else:
+            emitted = None
+        res.append((out[:M].clone(), ssq_o[:, :M].clone(), emitted))
+    (o0, s0, e0), (o1, s1, e1) = res
+    assert torch.equal(o0, o1) and torch.equal(s0, s1)
+    if e0 is not None:
+        assert torch.equal(e0, e1)
+        assert e0.abs().max().item() > 0
+    # and the values are right (float64), not merely equal
+    if epi == "store":
+        xd = x_in.double()
+        ref = (xd @ W.double()) * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+        assert (o1.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    elif resid:
+        ref = x0[:M].double() + x_in.double() @ W.double()
+        assert (o1.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("kvd,B,cur", [("bf16", 4, 300), ("f32", 3, 70), ("bf16", 8, 33)])
+def test_act_f32_attention_output_equals_planes(kvd, B, cur):
+    """dia_attn_args.act_f32: the attention output as fp32 tiles holds exactly what the three planes sum to"""
+    d = dev()
+    torch.manual_seed(cur + B)
+    R, QH, KVH, T = 2 * B, 16, 4, 512
+    nq = (QH + 2 * KVH) * 128
+    qkv = torch.randn(R, nq, device=d)
+    kdt = torch.float32 if kvd == "f32" else torch.bfloat16
+    kc0 = torch.randn(R, KVH, T, 128, device=d).to(kdt)
+    vc0 = torch.randn(R, KVH, T, 128, device=d).to(kdt)
+    blocked = kvd == "bf16"
+    if blocked:
+        vc0 = lay.v_to_blocked(vc0)
+    cos, sin = [t.to(d) for t in lay.rope_tables(T + 1, 128, 1, 10000)]
+    curs = torch.full((B,), cur, dtype=torch.int32, device=d)
+    mt = (R + 15) // 16
+    outs = []
+    for f32 in (0, 1):
+        kc, vc = kc0.clone(), vc0.clone()
+        P = torch.zeros(3, mt, QH * 4, 64, 8, dtype=torch.bfloat16, device=d)
+        a = hb.AttnArgs()
+        a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_SELF, (0 if kvd == "f32" else 1), KVH, 4, R, T
+        a.q, a.ldq, a.q_off, a.k_off, a.v_off = hb.ptr(qkv), nq, 0, QH * 128, (QH + KVH) * 128
+        a.kc, a.vc, a.cur = hb.ptr(kc), hb.ptr(vc), hb.ptr(curs)
+        a.cos_t, a.sin_t = hb.ptr(cos), hb.ptr(sin)
+        a.P, a.p_plane_stride, a.p_ktiles, a.act_f32 = hb.ptr(P), P[0].numel(), P.shape[2], f32
+        scr = torch.zeros(hb.lib().dia_attn_scratch_floats(R, KVH, T), device=d)
+        tk = torch.zeros(R * KVH, dtype=torch.int32, device=d)
+        a.scratch, a.tickets, a.v_blocked = hb.ptr(scr), hb.ptr(tk), int(blocked)
+        hb.check(hb.lib().dia_attn(C.byref(a), None), "dia_attn")
+        torch.cuda.synchronize()
+        if f32:
+            outs.append(lay.unpack_f32_tiles(P.view(torch.float32).reshape(-1)[: mt * QH * 4 * 512].reshape(mt, QH * 4, 64, 8), R, QH * 128))
+        else:
+            outs.append(lay.unpack_planes(P, R, QH * 128))
+    assert torch.equal(outs[0], outs[1]) and outs[0].abs().max().item() > 0
