@@ -2,9 +2,11 @@
 # regenerates the per-round evidence under gpurun_out/prof (copy what is judged into profiles/)
 #   scratch/profile_round.sh r02
 set -e
+#   scratch/profile_round.sh r02 pmc      (only the counter passes + traffic.json)
 R=${1:-r02}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof; mkdir -p $O
 cd $GRAFT_REPO_ROOT
+if [ "$2" != "pmc" ]; then
 python bench.py 2>/dev/null | tail -1 > $O/${R}_bench_default.json; echo "bench default (batch 1 + configs) done"
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${R}_bench_driver_style.json; echo "bench driver-style done"
 python bench.py --batch 8 --cpu-steps 0 2>/dev/null | tail -1 > $O/${R}_bench_batch8.json; echo "bench b8 done"
@@ -18,9 +20,13 @@ for cfg in "1:" "8:--batch 8" "8p:--batch 8 --pruned 0.5"; do
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$tag -- python3 $GRAFT_REPO_ROOT/bench.py $args --cpu-steps 0 --no-configs 2>/dev/null | tail -1 > $O/${R}_bench_batch${tag}_under_rocprof.json
   cp /tmp/rp_$tag/*/*_kernel_stats.csv $O/${R}_kernel_stats_batch$tag.csv; echo "rocprof $tag done"
 done
+fi
+cd /tmp && export TMPDIR=/tmp
+# (--preheat 0: the counter passes do not time anything, and rocprofv3 --pmc segfaults when a session is torn down and a second
+# one built in the profiled process)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-steps 0 --profile-steps 0 --no-configs > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-steps 0 --profile-steps 0 --no-configs --preheat 0 > /dev/null 2>&1
   python3 - <<PY
 import csv, glob, collections
 f = glob.glob("/tmp/pmc_$c/*/*counter_collection.csv")[0]
