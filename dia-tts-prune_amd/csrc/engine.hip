@@ -71,12 +71,8 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   const long xs = mt * xkt * 512, as = mt * akt * 512, hs = mt * hkt * 512;   // plane strides (elements)
   const int nqkv = (d.q_heads + 2 * d.kv_heads) * 128;
   int n = 0, rc;
-  // activation format per producer -> consumer edge (common.hpp): fp32 tiles from 5 rows on — except into a GEMM that runs the
-  // persistent 8-wave x 8-k-tile form at one m-tile (dense wi, the logits head): that form sits at the 256-VGPR limit and the
-  // in-register plane split spills (wi 16.9 -> 22.6 us, logits 11.4 -> 16.7 with fp32 input); it keeps reading planes
+  // activation format of every producer -> consumer edge (common.hpp): fp32 tiles from 5 rows on, three planes below
   const int F = d.act_f32 ? 1 : 0;
-  auto persistent8 = [&](int kt, int ns) { return R <= 16 && kt == 64 && ns > 256; };
-  const int LG = (F && !persistent8(d.kt_logits, d.ns_logits)) ? 1 : 0;
   // 17..32 rows: every GEMM may split K inside dia_gemm (k_gemm32 / k_gemm32m) when it is handed the scratch
   const bool two_tiles = R > 16 && R <= 32 && d.sk_scratch && d.sk_tickets && d.sk_scratch_floats > 0;   // (k_gemm32 / k_gemm32m / blk32 only)
   auto lend_scratch = [&](dia_gemm_args& g) {
@@ -85,8 +81,6 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
 
   for (int l = 0; l < d.n_layer; ++l) {
     const dia_dec_layer& L = e->layers[l];
-    const int WI = (F && !persistent8(L.kt_wi, L.ns_wi)) ? 1 : 0;      // format of the edge co -> wi
-    const int XO = (l + 1 < d.n_layer) ? F : LG;                       // format of the edge wo -> next qkv / logits
     dia_gemm_args g = {};
     // q/k/v projection of the pre-SA-normed row (layers.py:541, 273-275)
     g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
@@ -142,7 +136,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.ssq_ld = d.rows_pad; g.out = d.x; g.ldo = d.D; g.gnext = L.g_mlp; g.cmap = L.cmap_mlp;
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     lend_scratch(g);
-  g.act_f32 = F | (WI << 1); // x out in the format wi reads
+  g.act_f32 = 3 * F;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // SwiGLU MLP (layers.py:95-104)
@@ -197,7 +191,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
       e->mlp_fused = 0;                      // not available for this model: do not try again
     }
     lend_scratch(gi);
-    gi.act_f32 = WI | (F << 1); g.act_f32 = F | (XO << 1);      // wi: x in, hidden out; wo: hidden in, x out
+    gi.act_f32 = 3 * F; g.act_f32 = 3 * F;
     if ((rc = dia_gemm(&gi, st))) return rc; mark(e, n++);
     rc = dia_gemm(&g, st);
     if (rc == DIA_E_ARG && g.sk > 1) {
@@ -215,7 +209,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
   g.out = d.logits; g.ldo = d.ld_logits;
   lend_scratch(g);
-  g.act_f32 = LG;
+  g.act_f32 = F;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
   if (with_sampler) {
     if ((rc = dia_sample(&d.sample, st))) return rc; mark(e, n++);

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
 #define DIA_Z_TEMPORAL 1
 #endif
 constexpr bool ZTEMPORAL = DIA_Z_TEMPORAL != 0;
-template <int NW, int KPW, bool MULTI, bool MZ = false, bool AF32 = false, bool PF32 = false>
+template <int NW, int KPW, bool MULTI, bool MZ = false, bool AF32 = false, bool PF32 = false, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
                                                     int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
   // (leading arguments = fields of p, preloaded into SGPRs: see k_gemv_small)
@@ -370,7 +370,28 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
     xpre1 = p.out[(long)(r16 < p.M ? r16 : 0) * p.ldo + n];
     gpre1 = p.gnext[n];
   };
-  if (resid && r_thread) load_resid(blockIdx.x);
+  // 17..128 rows (MZ): the tail of round 1 — 32 threads, 8 tile elements each through the shared epilogue.  The element-per-thread
+  // tail below is worth 4 % at 16 rows, but it takes the persistent form from 231 VGPRs to the 256 limit with 200 B of scratch
+  // per lane, and at 2..8 m-tiles EVERY launch runs that form: batch 16 8 618 -> 7 100 frames/s, batch 32 12 836 -> 9 300.
+  const int e_r = (tid >> 1) & 15, e_half = tid & 1;
+  const bool e_thread = tid < 32, e_live = e_thread && e_r < p.M;
+  float xpre8[8], gpre8[8];
+  auto load_resid8 = [&](int strip) {
+    const int n0 = strip * 16 + e_half * 8;
+    const float* o = p.out + (long)(e_live ? e_r : 0) * p.ldo + n0;
+    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+    xpre8[0] = xa.x; xpre8[1] = xa.y; xpre8[2] = xa.z; xpre8[3] = xa.w;
+    xpre8[4] = xb.x; xpre8[5] = xb.y; xpre8[6] = xb.z; xpre8[7] = xb.w;
+    const float4 ga = *reinterpret_cast<const float4*>(p.gnext + n0), gb = *reinterpret_cast<const float4*>(p.gnext + n0 + 4);
+    gpre8[0] = ga.x; gpre8[1] = ga.y; gpre8[2] = ga.z; gpre8[3] = ga.w;
+    gpre8[4] = gb.x; gpre8[5] = gb.y; gpre8[6] = gb.z; gpre8[7] = gb.w;
+  };
+  // (the persistent 8 x 8 form with fp32 input takes that tail as well — unless it runs the strip-pair split-K below)
+  // PAIR (host-selected instantiation): split-K with exactly two strips per workgroup, gridDim.y > 1 && 2 * gridDim.x == nstrips
+  constexpr bool ZTAIL8 = MULTI && !MZ && !PAIR && KPW == 8 && AF32;
+  constexpr bool pair = PAIR;
+  if constexpr (MZ || ZTAIL8) { if (resid && e_thread) load_resid8(blockIdx.x); }
+  else { if (resid && r_thread) load_resid(blockIdx.x); }
   __builtin_amdgcn_sched_barrier(0);
   load_strip(b0, blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
@@ -386,6 +407,36 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
     s0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x141, 0xF, 0xF, true));
     if (tid < 128 && s_part == 0) inv_s[s_row] = has_norm ? rsqrtf(s0 * p.inv_d + p.eps) : 1.0f;
   }
+
+  auto run_ztail = [&]() {
+    auto body_z = [&](bf16x8* bc, bf16x8* bn, int strip) {
+      const int next = strip + G;
+      if constexpr (MULTI) { if (next < p.nstrips) load_strip(bn, next); }
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int i = 0; i < KPW; ++i)
+#pragma unroll
+        for (int pl = 0; pl < DIA_NPLANES; ++pl)
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], bc[i], acc[0], 0, 0, 0);
+      reduce_to_tile<1, NW, true>(acc, red, tile, tid, lane, w);
+      const bool last_slice = splitk_combine(p, tile, strip, tid, &sk_flag);      // workgroup-uniform; true without split-K
+      if (e_thread) {
+        const int n0 = strip * 16 + e_half * 8;
+        if (last_slice) run_epilogue(p, tile + e_r * 17, inv_s[e_r], e_r, n0, e_half, strip, e_live, xpre8, gpre8);
+        if (MULTI && next < p.nstrips && resid) load_resid8(next);
+      }
+    };
+    if constexpr (MULTI) {
+      for (int strip = blockIdx.x; strip < p.nstrips; strip += 2 * G) {
+        body_z(b0, b1, strip);
+        if (strip + G < p.nstrips) body_z(b1, b0, strip + G);
+      }
+    } else {
+      body_z(b0, b1, blockIdx.x);
+    }
+  };
+  if constexpr (MZ) { run_ztail(); return; }
+  if constexpr (ZTAIL8) { run_ztail(); return; }
 
   // Cross-wave sum + epilogue, one tile element per thread (256 threads): the NW partial tiles go to LDS whole, a thread adds
   // the partials of ITS element in wave order (one barrier, double-buffered over the strips of the persistent form)
@@ -503,8 +554,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   // CU, one round): both tiles are computed first and handed over TOGETHER — one slab publication, one ticket, one merge
   // by the last arriver — instead of one dependent hand-off chain per strip.  (512 one-strip workgroups at 160 VGPRs run
   // in two rounds, one workgroup per CU: 14.3 us; a hand-off per strip inside the persistent loop: 14.5 us.)
-  if constexpr (MULTI) {
-    if (gridDim.y > 1 && 2 * G == p.nstrips) {
+  if constexpr (PAIR) {
+    {
       const int s0 = blockIdx.x, s1 = blockIdx.x + G;
       float xpreB = 0.f, gpreB = 1.f;
       if (resid && r_thread) { const float xa = xpre1, ga = gpre1; load_resid(s1); xpreB = xpre1; gpreB = gpre1; xpre1 = xa; gpre1 = ga; }
@@ -573,6 +624,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
       lds_barrier();
       if (r_thread) { v0 = tile[r16 * 17 + c16]; v1 = tile1[r16 * 17 + c16]; }
       finish(s0, v0, xpre1, gpre1);
+      lds_barrier();        // the first tile's staged planes have left LDS before the second tile's values overwrite them
       finish(s1, v1, xpreB, gpreB);
       STAMP(5);
       return;
@@ -835,6 +887,8 @@ int launch_g16(const GemmK& k, hipStream_t st) {
       int gx = (k.nstrips + spw - 1) / spw;
       if (mz >= 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
       if (mz > 1) launch_small_kernel<k_gemm16<NW, KPW, true, true, AF32, PF32>>(dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
+      else if (KPW == 8 && sk > 1 && 2 * gx == k.nstrips)      // strip pairs handed over together (wo at 5..16 rows)
+        launch_small_kernel<k_gemm16<NW, (KPW == 8 ? 8 : KPW), true, false, AF32, PF32, KPW == 8>>(dim3(gx, sk), dim3(NW * 64), smem, st, k);
       else launch_small_kernel<k_gemm16<NW, KPW, true, false, AF32, PF32>>(dim3(gx, sk), dim3(NW * 64), smem, st, k);
       return dia_check_launch("k_gemm16");
     }
@@ -861,10 +915,7 @@ int launch_g16_any(const GemmK& k, int nw, int sk, hipStream_t st, bool& handled
       if (kpw == 7) return launch_g16<8, 7, true, true>(k, st);
       if (kpw == 8) return launch_g16<8, 8, true, true>(k, st);
     }
-    // mixed formats exist where the step needs them: around the persistent 8 x 8 forms, which stay on planes (engine.hip)
-    if (nw == 8 && kpw == 8 && k.a_f32 && emits && !pf) return launch_g16<8, 8, true, false>(k, st);
-    if (nw == 8 && kpw == 8 && !k.a_f32 && pf) return launch_g16<8, 8, false, true>(k, st);
-    handled = false;
+    handled = false;                                   // mixed formats: the generic kernel (run-time flags)
     return DIA_OK;
   }
   if (nw == 16) {

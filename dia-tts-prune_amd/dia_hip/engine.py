@@ -299,7 +299,8 @@ class DecodeSession:
         # them through LDS; from 5 rows on fp32 tiles in the same buffers (4 instead of 6 bytes per value: every workgroup of
         # the 16-row GEMM pulls the whole activation matrix, 192 KB at batch 8, and splits the planes in registers — same
         # arithmetic).  Tuning knob act_f32=0 keeps the planes.
-        self.act_f32 = int(self.R > 4 and hb.get_tuning("act_f32") != 0)
+        t_ = hb.get_tuning("act_f32")
+        self.act_f32 = int(self.R > 4 and t_ != 0)
         self.planes_x = z(3, mt, self.xkt, 64, 8, dt=torch.bfloat16)
         self.planes_a = z(3, mt, self.akt, 64, 8, dt=torch.bfloat16)
         self.planes_h = z(3, mt, self.hkt, 64, 8, dt=torch.bfloat16)
