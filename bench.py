@@ -295,7 +295,9 @@ def main():
     out = {
         "metric": "audio-codec frames/sec (Dia-1.6B decode, whole job)", "value": round(value, 2), "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        # N > 1 without --batch: BASELINE configs[4], 64 utterances in all over the N GPUs = fixed total work ("strong");
+        # an explicit --batch fixes the per-GPU work ("weak"), and so does the single-GPU line
+        "scaling": "strong" if (world > 1 and args.batch <= 0) else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": workload, "batch_per_gpu": batch, "parallelism": f"dp{world}" if world > 1 else "single"},
         "frames_per_s_per_gpu": round(value / world, 2), "rtf_per_gpu": round(value / world / batch / FRAME_RATE, 3),
         "rtf_aggregate": round(value / FRAME_RATE, 2),
