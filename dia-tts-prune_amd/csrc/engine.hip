@@ -89,6 +89,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.out = d.qkv; g.ldo = nqkv; g.strip_map = L.smap_qkv;
     lend_scratch(g);
   g.act_f32 = F;            // reads x as fp32 tiles
+  g.w_planes = d.w_planes;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     dia_attn_args a = {};
@@ -109,6 +110,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     lend_scratch(g);
   g.act_f32 = 3 * F;        // attention output in, x out: both fp32 tiles
+  g.w_planes = d.w_planes;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // cross-attention query (layers.py:273, 278)
@@ -119,6 +121,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.out = d.qc; g.ldo = d.cq_heads * 128; g.strip_map = L.smap_cq;
     lend_scratch(g);
   g.act_f32 = F;
+  g.w_planes = d.w_planes;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     a = {};
@@ -137,6 +140,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     lend_scratch(g);
   g.act_f32 = 3 * F;
+  g.w_planes = d.w_planes;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
 
     // SwiGLU MLP (layers.py:95-104)
@@ -182,7 +186,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     // opt-in (tuning knob mlp_fuse, EXPERIMENTS=1 builds), batch 1: wi and wo in one persistent launch (dia_mlp_fused).  Anything it refuses
     // (rows, shapes, CU count) takes the two launches below.
-    if (e->mlp_fused != 0 && R <= 2 && d.mlp_barrier && !L.cmap_mlp) {
+    if (e->mlp_fused != 0 && R <= 2 && d.mlp_barrier && !L.cmap_mlp && d.w_planes <= 1) {
       dia_gemm_args go = g;
       go.sk = 2; go.sk_scratch = d.sk_scratch; go.sk_tickets = d.sk_tickets; go.nw = 0; go.spw = 0;
       rc = dia_mlp_fused(&gi, &go, d.mlp_barrier, st);
@@ -191,7 +195,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
       e->mlp_fused = 0;                      // not available for this model: do not try again
     }
     lend_scratch(gi);
-    gi.act_f32 = 3 * F; g.act_f32 = 3 * F;
+    gi.act_f32 = 3 * F; g.act_f32 = 3 * F; gi.w_planes = d.w_planes; g.w_planes = d.w_planes;
     if ((rc = dia_gemm(&gi, st))) return rc; mark(e, n++);
     rc = dia_gemm(&g, st);
     if (rc == DIA_E_ARG && g.sk > 1) {
@@ -210,6 +214,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   g.out = d.logits; g.ldo = d.ld_logits;
   lend_scratch(g);
   g.act_f32 = F;
+  g.w_planes = d.w_planes;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
   if (with_sampler) {
     if ((rc = dia_sample(&d.sample, st))) return rc; mark(e, n++);

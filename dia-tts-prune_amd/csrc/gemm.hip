@@ -63,7 +63,26 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
   const bool live = e_thread && m < p.M;
   float xpre[8], gpre[8];
 
-  if constexpr (KPW > 0) {
+  // fp32 weights as three bf16 planes (w_planes == 3: hi, mid, lo tile sets back to back): the K loop below once per plane,
+  // into the same accumulators — 9 exact bf16 products per fp32 x fp32 one
+  if (p.w_planes > 1) {
+    prefetch_epilogue<MT, NW * 64>(p, tid, mt0, m, n0, live, xpre, gpre, inv_s);
+    const int kt1 = min(kt0 + kpw, p.KT);
+    for (int pw = 0; pw < p.w_planes; ++pw) {
+      const bf16x8* Wp = Wt + pw * (p.w_plane_stride / 8);
+      for (int kt = kt0; kt < kt1; ++kt) {
+        const bf16x8 bb = DIA_WLOAD(Wp + (long)kt * 64);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          bf16x8 a3[DIA_NPLANES];
+          load_afrag3(p, aoff[mt] + (long)kt * 512, a3[0], a3[1], a3[2]);
+#pragma unroll
+          for (int pl = 0; pl < DIA_NPLANES; ++pl)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[pl], bb, acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  } else if constexpr (KPW > 0) {
     bf16x8 b[KPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) b[i] = DIA_WLOAD(Wt + (long)(kt0 + i) * 64);
@@ -1112,6 +1131,15 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   }
   GemmK k;
   fill_gemmk(a, k);
+  if (a->w_planes > 1) {      // fp32 weights as three planes: the generic kernel, whatever the shape (exactness, not speed)
+    if (a->w_planes != 3) return dia_fail(DIA_E_ARG, "dia_gemm: w_planes must be 0, 1 or 3");
+    const int mt_ = (a->M + 15) / 16;
+    const int nw_ = (a->KT % 8 == 0) ? 8 : 4;
+    hipStream_t st_ = (hipStream_t)stream;
+    if (mt_ == 1) return launch_nw<1>(k, nw_, 1, st_);
+    if (mt_ == 2) return launch_nw<2>(k, nw_, 1, st_);
+    return launch_nw<4>(k, nw_, (mt_ + 3) / 4, st_);
+  }
   const bool fast_epi = a->epi != DIA_EPI_CROSSKV && !(a->epi == DIA_EPI_RESID_EMIT && !a->gnext);
   int nw = a->nw;
   if (nw == 0) {

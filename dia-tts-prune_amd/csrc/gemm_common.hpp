@@ -51,6 +51,7 @@ struct GemmK {
   const unsigned char* sp_blocks; const unsigned int* sp_toff;   // zero-skipping weight stream (k_gemv_sparse)
   int mz;                                  // host side only: m-tiles a k_gemm16 launch covers through gridDim.z (0/1 = one)
   int a_f32, p_f32;                        // A / P are fp32 activation tiles (common.hpp) instead of three bf16 planes
+  int w_planes; long w_plane_stride;       // k_gemm only: hi / mid / lo planes of fp32 weights, one tile set each
 };
 
 // the three plane fragments of the A operand at element offset `off` inside a plane / an fp32 tile set
@@ -344,6 +345,7 @@ inline int fill_gemmk(const dia_gemm_args* a, GemmK& k) {
   k.sp_blocks = (const unsigned char*)a->sp_blocks; k.sp_toff = (const unsigned int*)a->sp_toff;
   k.mz = 0;
   k.a_f32 = a->act_f32 & 1; k.p_f32 = (a->act_f32 >> 1) & 1;
+  k.w_planes = a->w_planes > 1 ? a->w_planes : 1; k.w_plane_stride = (long)a->KT * a->nstrips * 512;
   return DIA_OK;
 }
 

@@ -14,7 +14,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIA_HIP_LIB") or os.path.join(_HERE, "libdia_hip.so")   # override: experiments only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 KV_F32, KV_BF16 = 0, 1
 EPI_SCALE_STORE, EPI_RESID_EMIT, EPI_SWIGLU_EMIT, EPI_CROSSKV = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
@@ -44,7 +44,7 @@ class GemmArgs(C.Structure):
         ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p), ("sk", C.c_int32), ("kv_vblocked", C.c_int32),
         ("row_b", C.c_void_p), ("seg_off", C.c_void_p), ("sk_scratch_floats", C.c_int64),
         ("sp_blocks", C.c_void_p), ("sp_toff", C.c_void_p),
-        ("act_f32", C.c_int32), ("_pad_act", C.c_int32),
+        ("act_f32", C.c_int32), ("w_planes", C.c_int32),
     ]
 
 
@@ -135,7 +135,7 @@ class EngineDesc(C.Structure):
         ("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("text_len", C.c_void_p),
         ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p),
         ("attn_scratch", C.c_void_p), ("attn_tickets", C.c_void_p), ("sk_scratch_floats", C.c_int64), ("mlp_barrier", C.c_void_p),
-        ("act_f32", C.c_int32), ("_pad_act", C.c_int32),
+        ("act_f32", C.c_int32), ("w_planes", C.c_int32),
         ("sample", SampleArgs),
     ]
 

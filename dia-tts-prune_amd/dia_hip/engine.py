@@ -47,9 +47,16 @@ class TiledW:
 class DeviceWeights:
     """Checkpoint -> kernel layouts, resident in HBM (bf16 tiles; norms / embeddings fp32)."""
 
-    def __init__(self, cfg: DiaConfig, sd: Dict[str, torch.Tensor], device: torch.device, compact: str = "auto"):
+    def __init__(self, cfg: DiaConfig, sd: Dict[str, torch.Tensor], device: torch.device, compact: str = "auto",
+                 weight_planes: int = 1):
         """compact: "auto" = drop structure that a structured-pruned checkpoint zeroed (decoder only),
-        "off" = keep every matrix at its checkpoint shape (zeros are streamed)."""
+        "off" = keep every matrix at its checkpoint shape (zeros are streamed).
+        weight_planes: 1 = every DenseGeneral kernel as ONE bf16 tile set (exact for bf16-representable checkpoints, the fast
+        kernels); 3 = the hi / mid / lo bf16 planes of the fp32 weights (exact for any checkpoint, 3x the bytes, the generic
+        kernel: the parity configuration of a genuine fp32 checkpoint)."""
+        if weight_planes not in (1, 3):
+            raise ValueError("weight_planes must be 1 or 3")
+        self.weight_planes = weight_planes
         m, e, d = cfg.model, cfg.model.encoder, cfg.model.decoder
         if d.gqa_head_dim != HEAD_DIM or d.cross_head_dim != HEAD_DIM or e.head_dim != HEAD_DIM:
             raise hb.DiaHipError("the HIP attention kernels are built for head_dim 128 (Dia-1.6B)")
@@ -63,8 +70,8 @@ class DeviceWeights:
         self.max_weight_rounding = 0.0                  # largest |w - bf16(w)| / max|w| over the DenseGeneral kernels
 
         def tile(w2d) -> TiledW:
-            t, kt, ns = lay.tile_weight(w2d)
-            if w2d.numel():
+            t, kt, ns = lay.tile_weight_planes(w2d) if weight_planes == 3 else lay.tile_weight(w2d)
+            if w2d.numel() and weight_planes == 1:
                 err = (w2d - w2d.to(torch.bfloat16).to(w2d.dtype)).abs().max()
                 scale = w2d.abs().max()
                 if float(scale) > 0.0:
@@ -461,6 +468,7 @@ class DecodeSession:
         ed.sk_scratch_floats = self.sk_scratch.numel()
         ed.mlp_barrier = hb.ptr(self.mlp_barrier)
         ed.act_f32 = self.act_f32
+        ed.w_planes = w.weight_planes
         ed.sample = self._sample_args()
         self._desc = ed
         hb.check(hb.lib().dia_engine_create(C.byref(ed), C.c_void_p(self.stream.cuda_stream), C.byref(self._engine)),
@@ -539,6 +547,7 @@ class DecodeSession:
                     g = hb.GemmArgs()
                     g.A, g.a_plane_stride, g.a_ktiles, g.M = (a_ptr if a_ptr is not None else hb.ptr(A)), A[0].numel(), a_kt, M
                     g.W, g.KT, g.nstrips, g.epi = hb.ptr(W.t), W.kt, W.ns, epi
+                    g.w_planes = w.weight_planes
                     sp = ssq_ptr if ssq_ptr is not None else hb.ptr(ssq)
                     if ssq_in:
                         g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = sp, E // 16, 1.0 / E, eps
@@ -600,7 +609,7 @@ class DecodeSession:
         """The batched MFMA prefill of the prompt rows needs bf16 caches with the blocked V layout and an
         uncompacted decoder; everything else replays the prompt rows through the decode step (first_step)."""
         return (any(f > 2 for f in self.first_steps) and self.v_blocked == 1 and not self.w.compacted and not self.teacher
-                and self.prompt_prefill != "replay")
+                and self.prompt_prefill != "replay" and self.w.weight_planes == 1)
 
     def _prompt_prefill(self, st):
         """Decoder.forward in prefill mode (layers.py:722-766) for the audio prompts of all utterances at once, with
@@ -645,6 +654,7 @@ class DecodeSession:
             g = hb.GemmArgs()
             g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), a_kt, Mp
             g.W, g.KT, g.nstrips, g.epi = hb.ptr(W.t), W.kt, W.ns, epi
+            g.w_planes = self.w.weight_planes
             if ssq_in:
                 g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq), D // 16, 1.0 / D, eps
             g.ssq_ld = Mp

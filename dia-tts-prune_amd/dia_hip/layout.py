@@ -34,6 +34,13 @@ def tile_weight(w2d: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
     return t.reshape(ns, kt, 64, 8).to(torch.bfloat16).contiguous(), kt, ns
 
 
+def tile_weight_planes(w2d: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
+    """[K, N] fp32 -> (bf16 tiles [3, N/16, K/32, 64, 8], K/32, N/16): the hi / mid / lo planes of the weights
+    (hi + mid + lo == w exactly), one tile set each, back to back — dia_gemm_args.w_planes = 3."""
+    planes = [tile_weight(pl.float()) for pl in split3(w2d.float())]
+    return torch.stack([t for t, _, _ in planes]).contiguous(), planes[0][1], planes[0][2]
+
+
 def untile_weight(tiles: torch.Tensor, K: int, N: int) -> torch.Tensor:
     ns, kt = tiles.shape[0], tiles.shape[1]
     w = tiles.float().reshape(ns, kt, 4, 16, 8).permute(1, 2, 4, 0, 3).reshape(kt * 32, ns * 16)

@@ -44,6 +44,10 @@ def _default_device() -> torch.device:
 
 
 class Dia:
+    # what compute_dtype="float32" does with a checkpoint that bf16 cannot hold: "exact" = three bf16 planes per weight
+    # (the reference's fp32 path, ~3x slower), "round" = one rounded bf16 tile set (fast; the load prints a warning)
+    fp32_weights = "exact"
+
     def __init__(self, config: DiaConfig, compute_dtype: Union[str, ComputeDtype] = ComputeDtype.FLOAT32,
                  device: Optional[torch.device] = None):
         """compute_dtype selects the K/V-cache precision: float32 keeps K/V in fp32 (the parity
@@ -61,6 +65,7 @@ class Dia:
         self.dac_model = None
         self.last_codes: Optional[np.ndarray] = None
         self.weights_rounded = False
+        self.weights_exact_planes = False
         hb.lib()                                        # fail now, not at first generate()
 
     # ------------------------------------------------------------------ loaders
@@ -79,15 +84,26 @@ class Dia:
             raise RuntimeError(f"Missing keys in checkpoint: {missing}")
         with torch.cuda.device(self.device):
             self.model = DeviceWeights(self.config, sd, self.device)
-        # DenseGeneral kernels are streamed as bf16 in every mode.  A checkpoint whose values are bf16-representable
-        # (bf16-trained weights stored as fp32, the synthetic ones) loses nothing; a genuine fp32 checkpoint is rounded
-        # once at load = the reference's bfloat16 configuration, NOT its float32 path: say so instead of silently
-        # missing the 1e-3 logit bound of compute_dtype="float32".
-        self.weights_rounded = self.model.max_weight_rounding > 0.0
-        if self.weights_rounded and self.compute_dtype == torch.float32:
-            print(f"Warning: checkpoint weights are not bf16-representable (largest relative rounding "
-                  f"{self.model.max_weight_rounding:.2e}); they are streamed as bf16, so compute_dtype='float32' here means "
-                  f"fp32 activations / accumulation / K/V over bf16-rounded weights, not the reference's fp32 weights.")
+            # DenseGeneral kernels are streamed as ONE bf16 tile set by the fast kernels.  A checkpoint whose values are
+            # bf16-representable (bf16-trained weights stored as fp32, the synthetic ones) loses nothing.  A genuine fp32
+            # checkpoint would be rounded once at load = the reference's bfloat16 configuration, NOT its float32 path:
+            #   compute_dtype="float32": the weights are kept as three bf16 planes (hi + mid + lo == w exactly) and run
+            #       through the generic kernel — the reference's fp32 arithmetic for ANY checkpoint, at about a third
+            #       of the speed (Dia.fp32_weights = "round" keeps the single rounded tile set and says so);
+            #   bfloat16 / float16: rounded once, like the reference's own low-precision modules.
+            self.weights_rounded = self.model.max_weight_rounding > 0.0
+            self.weights_exact_planes = False
+            if self.weights_rounded and self.compute_dtype == torch.float32:
+                if self.fp32_weights == "exact":
+                    rounding = self.model.max_weight_rounding
+                    self.model = DeviceWeights(self.config, sd, self.device, weight_planes=3)
+                    self.weights_rounded, self.weights_exact_planes = False, True
+                    print(f"Note: checkpoint weights are not bf16-representable (largest relative rounding {rounding:.2e}): "
+                          f"compute_dtype='float32' keeps them exact as three bf16 planes (3x the weight traffic, generic kernel).")
+                else:
+                    print(f"Warning: checkpoint weights are not bf16-representable (largest relative rounding "
+                          f"{self.model.max_weight_rounding:.2e}); they are streamed as bf16, so compute_dtype='float32' here means "
+                          f"fp32 activations / accumulation / K/V over bf16-rounded weights, not the reference's fp32 weights.")
 
     @classmethod
     def from_state_dict(cls, config: DiaConfig, state_dict: Dict[str, torch.Tensor],

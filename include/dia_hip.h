@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DIA_ABI_VERSION 4
+#define DIA_ABI_VERSION 5
 
 #define DIA_OK 0
 #define DIA_E_ARG (-1)     /* bad argument / unsupported shape */
@@ -133,7 +133,11 @@ typedef struct {
    * K / 32 / sk == 64; anything else runs the generic kernel.  Not available in the M <= 4 kernel (dia_gemm then takes the 16-row
    * one) nor in the tiled prefill kernel. */
   int32_t act_f32;
-  int32_t _pad_act;
+  /* 0 / 1: W holds one bf16 tile set (exact for bf16-representable checkpoints).  3: W holds THREE tile sets back to back, the
+   * hi / mid / lo bf16 planes of fp32 weights (hi + mid + lo == w exactly; plane stride = KT * nstrips * 512 elements): the
+   * products of a genuine fp32 checkpoint, exact like the activations' — through the generic kernel only (no split-K, no
+   * persistent forms): the parity configuration for checkpoints that bf16 cannot hold, not a fast path. */
+  int32_t w_planes;
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
@@ -370,7 +374,7 @@ typedef struct {
   int32_t* mlp_barrier;     /* 2 int32 zeroed by the caller once: dia_mlp_fused's barrier words (NULL = never fuse) */
   int32_t act_f32;          /* 1: planes_x / planes_a / planes_h carry fp32 activation tiles (dia_gemm_args.act_f32); needs
                              * more than 4 rows (B >= 3) and sample.embed.act_f32 == 1 */
-  int32_t _pad_act;
+  int32_t w_planes;         /* 0 / 1, or 3: every weight pointer holds three bf16 planes of fp32 weights (dia_gemm_args.w_planes) */
   dia_sample_args sample;   /* sampler + FSM + embedding parameters */
 } dia_engine_desc;
 

@@ -1003,3 +1003,59 @@ def test_act_f32_attention_output_equals_planes(kvd, B, cur):
         else:
             outs.append(lay.unpack_planes(P, R, QH * 128))
     assert torch.equal(outs[0], outs[1]) and outs[0].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("M,K,N,epi", [(2, 2048, 2048, "resid"), (2, 512, 1024, "store"), (16, 1024, 4096, "swiglu"), (40, 512, 512, "resid"),
+                                       (130, 256, 320, "store")])
+def test_gemm_fp32_weights_as_three_planes(M, K, N, epi):
+    """dia_gemm_args.w_planes = 3: fp32 weights that bf16 cannot hold, streamed as hi / mid / lo tile sets — the products are
+    those of fp32 x fp32 (float64 reference to 2e-6 of the output scale; the single rounded tile set misses by ~4e-3)."""
+    d = dev()
+    torch.manual_seed(M + K + N)
+    x = torch.randn(M, K, device=d)
+    W = torch.randn(K, N, device=d) * 0.05                      # NOT bf16-representable
+    Wt3, kt, ns = lay.tile_weight_planes(W)
+    mpad = (M + 15) // 16 * 16
+    A = lay.pack_planes(x)
+    g = hb.GemmArgs()
+    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+    g.W, g.KT, g.nstrips, g.w_planes = hb.ptr(Wt3), kt, ns, 3
+    g.ssq_ld = mpad
+    xd, Wd = x.double(), W.double()
+    if epi == "store":
+        ssq = strip_ssq(x, mpad)
+        out = torch.zeros(mpad, N, device=d)
+        g.epi, g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.out, g.ldo = hb.EPI_SCALE_STORE, hb.ptr(ssq), ssq.shape[0], 1.0 / K, 1e-5, hb.ptr(out), N
+        ref = (xd @ Wd) * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+        get = lambda: out[:M].double()
+    elif epi == "resid":
+        x0 = torch.randn(mpad, N, device=d)
+        out = x0.clone()
+        gn = torch.ones(N, device=d)
+        P = torch.zeros(3, mpad // 16, N // 32, 64, 8, dtype=torch.bfloat16, device=d)
+        so = torch.zeros(ns, mpad, device=d)
+        g.epi, g.out, g.ldo, g.gnext, g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.EPI_RESID_EMIT, hb.ptr(out), N, hb.ptr(gn), hb.ptr(P), P[0].numel(), N // 32, hb.ptr(so)
+        ref = x0[:M].double() + xd @ Wd
+        get = lambda: out[:M].double()
+    else:
+        ssq = strip_ssq(x, mpad)
+        P = torch.zeros(3, mpad // 16, N // 64, 64, 8, dtype=torch.bfloat16, device=d)
+        g.epi, g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.EPI_SWIGLU_EMIT, hb.ptr(ssq), ssq.shape[0], 1.0 / K, 1e-5
+        g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), N // 64
+        xn = xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+        Wg = Wd.reshape(K, N // 16, 2, 8)                        # strips of 8 gate + 8 up columns
+        ref = (torch.nn.functional.silu(xn @ Wg[:, :, 0].reshape(K, -1)) * (xn @ Wg[:, :, 1].reshape(K, -1)))
+        get = lambda: lay.unpack_planes(P, M, N // 2).double()
+    hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+    torch.cuda.synchronize()
+    err = (get() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err <= 2e-6, err
+    # the rounded single tile set on the same problem, for scale
+    Wt1, _, _ = lay.tile_weight(W)
+    g.W, g.w_planes = hb.ptr(Wt1), 0
+    if epi == "resid":
+        out.copy_(x0)
+    hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+    torch.cuda.synchronize()
+    err1 = (get() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err1 > 20 * err, (err, err1)

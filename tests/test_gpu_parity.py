@@ -693,28 +693,50 @@ def test_full_size_bf16_kv_vs_oracle(full):
     assert out["bf16"][0] <= BF16_KV_LOGIT_BOUND_FULL and out["bf16"][1] >= 0.8
 
 
-def test_fp32_checkpoint_is_rounded_once_and_says_so(mid, capsys):
-    """A checkpoint whose weights are NOT bf16-representable (a genuine fp32 checkpoint): the DenseGeneral kernels are
-    streamed as bf16, so compute_dtype="float32" computes the reference's arithmetic over bf16-ROUNDED weights.  The load
-    says so; against the oracle on the rounded weights the 1e-3 bound holds with identical samples; against the oracle
-    on the unrounded fp32 weights the error is what weight rounding costs — measured here, documented in INTEGRATION.md."""
+def test_fp32_checkpoint_exact_planes_or_rounded_once(mid, capsys):
+    """A checkpoint whose weights are NOT bf16-representable (a genuine fp32 checkpoint).
+    compute_dtype="float32" (default, Dia.fp32_weights == "exact"): the DenseGeneral kernels are kept as three bf16 planes
+    (hi + mid + lo == w) and the logits meet the 1e-3 bound against the oracle ON THE FP32 WEIGHTS, samples identical — the
+    reference's float32 path for any checkpoint.  Dia.fp32_weights = "round": one bf16 tile set, rounded once, the load says
+    so; against the oracle on the rounded weights the bound holds, against the fp32 weights the error is what bf16 weights cost."""
     cfg, sd, _ = mid
     g = torch.Generator().manual_seed(3)
     raw = {k: (v + v.abs().mean() * 2.0 ** -10 * torch.randn(v.shape, generator=g)) if v.ndim >= 2 and "embedding" not in k else v.clone()
            for k, v in sd.items()}
     rounded = {k: (v.to(torch.bfloat16).float() if v.ndim >= 2 and "embedding" not in k else v) for k, v in raw.items()}
     assert any(not torch.equal(raw[k], rounded[k]) for k in raw)
+    mt = 24
+    r_raw, nz = oracle_run(cfg, raw, TEXTS[0], 42, mt)
+    # ---- exact: three planes
     dia = Dia.from_state_dict(cfg, raw, "float32", torch.device("cuda:0"))
     out = capsys.readouterr().out
-    assert dia.weights_rounded and "not bf16-representable" in out
-    assert not Dia.from_state_dict(cfg, sd, "float32", torch.device("cuda:0")).weights_rounded      # the synthetic ones are exact
-    mt = 24
+    assert dia.weights_exact_planes and not dia.weights_rounded and "three bf16 planes" in out
+    assert dia.model.weight_planes == 3
+    logits, res = teacher_forced(dia.model, cfg, [TEXTS[0]], [r_raw.tokens], [nz], mt)
+    e_exact = max(float(np.abs(logits[i][0] - r_raw.logits[i]).max()) for i in range(len(r_raw.logits)))
+    msg_exact = f"fp32 checkpoint, three weight planes: logits vs oracle on the fp32 weights {e_exact:.3e}"
+    assert e_exact <= LOGIT_TOL
+    for i, p_ in enumerate(r_raw.preds):
+        assert np.array_equal(res[0].preds[1 + i], p_), i
+    assert not Dia.from_state_dict(cfg, sd, "float32", torch.device("cuda:0")).weights_exact_planes     # the synthetic ones need no planes
+    # bfloat16 compute: rounded once like the reference's own bf16 modules, no planes
+    assert Dia.from_state_dict(cfg, raw, "bfloat16", torch.device("cuda:0")).model.weight_planes == 1
+    # ---- round: one tile set
+    Dia.fp32_weights = "round"
+    try:
+        capsys.readouterr()
+        dia = Dia.from_state_dict(cfg, raw, "float32", torch.device("cuda:0"))
+        out = capsys.readouterr().out
+    finally:
+        Dia.fp32_weights = "exact"
+    assert dia.weights_rounded and not dia.weights_exact_planes and "not bf16-representable" in out
     r_round, nz = oracle_run(cfg, rounded, TEXTS[0], 42, mt)
-    r_raw, _ = oracle_run(cfg, raw, TEXTS[0], 42, mt, forced_tokens=r_round.tokens)
+    r_raw2, _ = oracle_run(cfg, raw, TEXTS[0], 42, mt, forced_tokens=r_round.tokens)
     logits, res = teacher_forced(dia.model, cfg, [TEXTS[0]], [r_round.tokens], [nz], mt)
     e_round = max(float(np.abs(logits[i][0] - r_round.logits[i]).max()) for i in range(len(r_round.logits)))
-    e_raw = max(float(np.abs(logits[i][0] - r_raw.logits[i]).max()) for i in range(len(r_raw.logits)))
-    print(f"fp32 checkpoint: logits vs oracle on bf16-rounded weights {e_round:.3e}, vs oracle on the fp32 weights {e_raw:.3e}")
+    e_raw = max(float(np.abs(logits[i][0] - r_raw2.logits[i]).max()) for i in range(len(r_raw2.logits)))
+    print(msg_exact)
+    print(f"fp32 checkpoint, rounded once: logits vs oracle on bf16-rounded weights {e_round:.3e}, vs oracle on the fp32 weights {e_raw:.3e}")
     assert e_round <= LOGIT_TOL
     for i, p_ in enumerate(r_round.preds):
         assert np.array_equal(res[0].preds[1 + i], p_), i
