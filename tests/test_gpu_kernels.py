@@ -1050,6 +1050,24 @@ def test_gemm_fp32_weights_as_three_planes(M, K, N, epi):
     torch.cuda.synchronize()
     err = (get() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
     assert err <= 2e-6, err
+    # the same launch with fp32 activation tiles on both sides (what the engine passes from 5 rows on): identical bits
+    if M > 4:
+        first = get().clone()
+        A32 = lay.pack_planes(x)
+        A32.view(torch.float32).reshape(-1)[: A32[0].numel()] = lay.pack_f32_tiles(x).reshape(-1)
+        g.A, g.act_f32 = hb.ptr(A32), 3
+        if epi == "resid":
+            out.copy_(x0)
+        if epi != "store":
+            P.zero_()
+        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+        torch.cuda.synchronize()
+        if epi == "swiglu":
+            again = lay.unpack_f32_tiles(P.view(torch.float32).reshape(-1)[: (mpad // 16) * (N // 64) * 512].reshape(mpad // 16, N // 64, 64, 8), M, N // 2).double()
+        else:
+            again = get()
+        assert torch.equal(again, first)
+        g.A, g.act_f32 = hb.ptr(A), 0
     # the rounded single tile set on the same problem, for scale
     Wt1, _, _ = lay.tile_weight(W)
     g.W, g.w_planes = hb.ptr(Wt1), 0
