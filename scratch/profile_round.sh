@@ -22,8 +22,8 @@ for cfg in "1:" "8:--batch 8" "8p:--batch 8 --pruned 0.5"; do
 done
 fi
 cd /tmp && export TMPDIR=/tmp
-# (--preheat 0: the counter passes do not time anything, and rocprofv3 --pmc segfaults when a session is torn down and a second
-# one built in the profiled process)
+# (--preheat 0: the counter passes do not time anything, and rocprofv3 --pmc segfaults as soon as a second decode
+# session — a second captured graph — is built in the profiled process, whether or not the first was torn down)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-steps 0 --profile-steps 0 --no-configs --preheat 0 > /dev/null 2>&1
