@@ -186,7 +186,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     g.P = d.planes_x; g.p_plane_stride = xs; g.p_ktiles = xkt; g.ssq_out = d.ssq;
     // opt-in (tuning knob mlp_fuse, EXPERIMENTS=1 builds), batch 1: wi and wo in one persistent launch (dia_mlp_fused).  Anything it refuses
     // (rows, shapes, CU count) takes the two launches below.
-    if (e->mlp_fused != 0 && R <= 2 && d.mlp_barrier && !L.cmap_mlp && d.w_planes <= 1) {
+    if (e->mlp_fused != 0 && R <= 2 && d.mlp_barrier && !L.cmap_mlp && d.w_planes <= 1 && !d.act_f32) {
       dia_gemm_args go = g;
       go.sk = 2; go.sk_scratch = d.sk_scratch; go.sk_tickets = d.sk_tickets; go.nw = 0; go.spw = 0;
       rc = dia_mlp_fused(&gi, &go, d.mlp_barrier, st);
@@ -229,8 +229,8 @@ extern "C" int dia_engine_create(const dia_engine_desc* d, void* stream, dia_eng
   if (d->D % 32 != 0 || d->F % 32 != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: D and F must be multiples of 32");
   if (d->rows_pad < 2 * d->B || d->rows_pad % 16 != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: rows_pad must be 16*ceil(2B/16)");
   if (d->q_heads % d->kv_heads != 0) return dia_fail(DIA_E_ARG, "dia_engine_create: q_heads % kv_heads != 0");
-  if (d->act_f32 && (2 * d->B <= 4 || !d->sample.embed.act_f32))
-    return dia_fail(DIA_E_ARG, "dia_engine_create: act_f32 needs more than 4 rows and an embedding that writes fp32 tiles too");
+  if (d->act_f32 && !d->sample.embed.act_f32)
+    return dia_fail(DIA_E_ARG, "dia_engine_create: act_f32 needs an embedding that writes fp32 tiles too");
   if (!d->act_f32 && d->sample.embed.act_f32) return dia_fail(DIA_E_ARG, "dia_engine_create: the embedding writes fp32 tiles but the engine reads planes");
   if (!d->x || !d->planes_x || !d->planes_a || !d->planes_h || !d->ssq || !d->qkv || !d->qc || !d->logits || !d->cos_t ||
       !d->sin_t || !d->text_len || !d->w_logits || !d->g_final || !d->attn_scratch || !d->attn_tickets)

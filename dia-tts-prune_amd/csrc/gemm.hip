@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmK p) {
 // processor hands over in SGPRs at wave launch (kernarg preload, -mllvm -amdgpu-kernarg-preload-count=16) — the operand
 // and weight loads of the prologue then need no scalar load from the argument block, whose lines every CU of the grid
 // otherwise requests at the same moment (in-kernel stamps: 0.8 us from the start of a wave to its first weight load).
-template <int NW, int KPW, int RS, bool MULTI>
+template <int NW, int KPW, int RS, bool MULTI, bool AF32 = false, bool PF32 = false>
 __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
                                                         int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
   p.A = a_A; p.a_plane_stride = a_aps; p.W = a_W; p.KT = a_KT; p.M = a_M; p.epi = a_epi; p.nstrips = a_nstrips;
@@ -186,12 +186,28 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
   // (1) compact A image: chunk c = ((plane*KT + kt)*4 + kq)*RS + row, 16 bytes each
   constexpr int CH = (3 * KPW * RS + 15) / 16;        // chunks per thread = 3*KT*4*RS / NT
   constexpr int nchunks = DIA_NPLANES * KT * 4 * RS;
-  bf16x8 v0[CH];
+  // AF32: the image arrives as fp32 tiles (common.hpp) — 32 bytes per (k-tile, quarter, row) entry instead of three 16-byte plane
+  // chunks, a third less to pull before the barrier; the thread that loads an entry splits it into the three plane chunks
+  constexpr int nentries = KT * 4 * RS;
+  constexpr int CE = (KPW * RS + 15) / 16;           // entries per thread = KT*4*RS / NT
+  bf16x8 v0[AF32 ? 1 : CH];
+  float4 ex[AF32 ? CE : 1], ey[AF32 ? CE : 1];
+  if constexpr (AF32) {
+    const float* Af = reinterpret_cast<const float*>(p.A);
 #pragma unroll
-  for (int u = 0; u < CH; ++u) {
-    const int c = min(tid + u * NT, nchunks - 1);
-    const int row = c % RS, kq = (c / RS) & 3, kt = (c / (4 * RS)) % KT, pl = c / (4 * RS * KT);
-    v0[u] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)(ktg + kt) * 64 + row + 16 * kq) * 8);
+    for (int u = 0; u < CE; ++u) {
+      const int c = min(tid + u * NT, nentries - 1);
+      const int row = c % RS, kq = (c / RS) & 3, kt = c / (4 * RS);
+      const float4* src = reinterpret_cast<const float4*>(Af + ((long)(ktg + kt) * 64 + row + 16 * kq) * 8);
+      ex[u] = src[0]; ey[u] = src[1];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int c = min(tid + u * NT, nchunks - 1);
+      const int row = c % RS, kq = (c / RS) & 3, kt = (c / (4 * RS)) % KT, pl = c / (4 * RS * KT);
+      v0[u] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)(ktg + kt) * 64 + row + 16 * kq) * 8);
+    }
   }
   // (2) strip sums of squares for the row scale: 8 threads per row, up to 16 strips each per round
   const bool has_norm = p.ssq_in != nullptr;
@@ -221,9 +237,20 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
   __builtin_amdgcn_sched_barrier(0);
 #endif
   STAMP(1);
+  if constexpr (AF32) {
 #pragma unroll
-  for (int u = 0; u < CH; ++u)
-    if (tid + u * NT < nchunks) As[tid + u * NT] = v0[u];
+    for (int u = 0; u < CE; ++u)
+      if (tid + u * NT < nentries) {
+        const int c = tid + u * NT;                    // entry c of plane pl sits at chunk pl * nentries + c
+        bf16x8 h, mi, lo;
+        split3x8(ex[u], ey[u], h, mi, lo);
+        As[c] = h; As[nentries + c] = mi; As[2 * nentries + c] = lo;
+      }
+  } else {
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (tid + u * NT < nchunks) As[tid + u * NT] = v0[u];
+  }
   {
     float s0 = 0.f;
 #pragma unroll
@@ -280,7 +307,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
       if (r_thread) v = tile[(tid >> 4) * 17 + (tid & 15)];
     }
     if (r_thread) {
-      run_epilogue_rows<RS>(p, v, inv_s, tid, strip, xpre1, gpre1);
+      run_epilogue_rows<RS, PF32>(p, v, inv_s, tid, strip, xpre1, gpre1);
       if (MULTI && next < p.nstrips && resid) load_resid(next);      // residual operands of the next strip
     }
   };
@@ -995,7 +1022,7 @@ size_t small_smem(int nw, int KT, int rs) {     // KT = k-tiles one workgroup st
   return sizeof(f32x4) * nw * 64 + sizeof(float) * (16 * 17 + 16) + (size_t)DIA_NPLANES * KT * 4 * rs * 16;
 }
 
-template <int NW, int KPW, int RS>
+template <int NW, int KPW, int RS, bool F32 = false>
 int launch_small(const GemmK& k, hipStream_t st) {
   size_t smem = small_smem(NW, NW * KPW, RS);
   if (smem > 64 * 1024) {
@@ -1012,46 +1039,46 @@ int launch_small(const GemmK& k, hipStream_t st) {
   if (dia_tune(DIA_TUNE_GEMM_SPW) > 0) spw = dia_tune(DIA_TUNE_GEMM_SPW);
   const int grid = (k.nstrips + spw - 1) / spw;
   if (sk > 1) {
-    launch_small_kernel<k_gemv_small<NW, KPW, RS, false>>(dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
+    launch_small_kernel<k_gemv_small<NW, KPW, RS, false, F32, F32>>(dim3(k.nstrips, sk), dim3(NW * 64), smem, st, k);
     return dia_check_launch("k_gemv_small");
   }
   if (spw > 1) {
     if constexpr (KPW <= 16 && !(NW == 16 && KPW > 4))
-      launch_small_kernel<k_gemv_small<NW, KPW, RS, true>>(dim3(grid), dim3(NW * 64), smem, st, k);
+      launch_small_kernel<k_gemv_small<NW, KPW, RS, true, F32, F32>>(dim3(grid), dim3(NW * 64), smem, st, k);
     else
-      launch_small_kernel<k_gemv_small<NW, KPW, RS, false>>(dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+      launch_small_kernel<k_gemv_small<NW, KPW, RS, false, F32, F32>>(dim3(k.nstrips), dim3(NW * 64), smem, st, k);
   } else {
-    launch_small_kernel<k_gemv_small<NW, KPW, RS, false>>(dim3(k.nstrips), dim3(NW * 64), smem, st, k);
+    launch_small_kernel<k_gemv_small<NW, KPW, RS, false, F32, F32>>(dim3(k.nstrips), dim3(NW * 64), smem, st, k);
   }
   return dia_check_launch("k_gemv_small");
 }
 
-template <int RS>
+template <int RS, bool F32 = false>
 int launch_small_rs(const GemmK& k, int nw, int sk, hipStream_t st, bool& handled) {
   handled = true;
   const int kpw = (k.KT % (nw * sk) == 0) ? k.KT / (nw * sk) : 0;
   if (nw == 4) {
-    if (kpw == 4) return launch_small<4, 4, RS>(k, st);
-    if (kpw == 8) return launch_small<4, 8, RS>(k, st);
-    if (kpw == 16) return launch_small<4, 16, RS>(k, st);
+    if (kpw == 4) return launch_small<4, 4, RS, F32>(k, st);
+    if (kpw == 8) return launch_small<4, 8, RS, F32>(k, st);
+    if (kpw == 16) return launch_small<4, 16, RS, F32>(k, st);
   } else if (nw == 8) {
-    if (kpw == 2) return launch_small<8, 2, RS>(k, st);
-    if (kpw == 3) return launch_small<8, 3, RS>(k, st);      // 3, 5, 6, 7: K-compacted (pruned) shapes, K % 256 == 0
-    if (kpw == 4) return launch_small<8, 4, RS>(k, st);
-    if (kpw == 5) return launch_small<8, 5, RS>(k, st);
-    if (kpw == 6) return launch_small<8, 6, RS>(k, st);
-    if (kpw == 7) return launch_small<8, 7, RS>(k, st);
-    if (kpw == 8) return launch_small<8, 8, RS>(k, st);
-    if (kpw == 10) return launch_small<8, 10, RS>(k, st);    // 10, 12, 14: compacted hidden widths (multiples of 1024) under split-K 2
-    if (kpw == 12) return launch_small<8, 12, RS>(k, st);
-    if (kpw == 14) return launch_small<8, 14, RS>(k, st);
-    if (kpw == 16) return launch_small<8, 16, RS>(k, st);
-    if (kpw == 32) return launch_small<8, 32, RS>(k, st);
+    if (kpw == 2) return launch_small<8, 2, RS, F32>(k, st);
+    if (kpw == 3) return launch_small<8, 3, RS, F32>(k, st);      // 3, 5, 6, 7: K-compacted (pruned) shapes, K % 256 == 0
+    if (kpw == 4) return launch_small<8, 4, RS, F32>(k, st);
+    if (kpw == 5) return launch_small<8, 5, RS, F32>(k, st);
+    if (kpw == 6) return launch_small<8, 6, RS, F32>(k, st);
+    if (kpw == 7) return launch_small<8, 7, RS, F32>(k, st);
+    if (kpw == 8) return launch_small<8, 8, RS, F32>(k, st);
+    if (kpw == 10) return launch_small<8, 10, RS, F32>(k, st);    // 10, 12, 14: compacted hidden widths (multiples of 1024) under split-K 2
+    if (kpw == 12) return launch_small<8, 12, RS, F32>(k, st);
+    if (kpw == 14) return launch_small<8, 14, RS, F32>(k, st);
+    if (kpw == 16) return launch_small<8, 16, RS, F32>(k, st);
+    if (kpw == 32) return launch_small<8, 32, RS, F32>(k, st);
   } else if (nw == 16) {
-    if (kpw == 1) return launch_small<16, 1, RS>(k, st);
-    if (kpw == 2) return launch_small<16, 2, RS>(k, st);
-    if (kpw == 4) return launch_small<16, 4, RS>(k, st);
-    if (kpw == 8) return launch_small<16, 8, RS>(k, st);
+    if (kpw == 1) return launch_small<16, 1, RS, F32>(k, st);
+    if (kpw == 2) return launch_small<16, 2, RS, F32>(k, st);
+    if (kpw == 4) return launch_small<16, 4, RS, F32>(k, st);
+    if (kpw == 8) return launch_small<16, 8, RS, F32>(k, st);
   }
   handled = false;
   return DIA_OK;
@@ -1068,6 +1095,13 @@ int small_attr() {
     e[3] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
   }
   for (int i = 0; i < 4; ++i) if (e[i] != hipSuccess) return dia_fail_hip(e[i], "hipFuncSetAttribute(k_gemv_small)");
+  e[0] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 2, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  e[1] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 4, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  if constexpr (KPW <= 16 && !(NW == 16 && KPW > 4)) {
+    e[2] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 2, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    e[3] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_small<NW, KPW, 4, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  }
+  for (int i = 0; i < 4; ++i) if (e[i] != hipSuccess) return dia_fail_hip(e[i], "hipFuncSetAttribute(k_gemv_small, fp32 tiles)");
   return DIA_OK;
 }
 
@@ -1160,11 +1194,15 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   const int sk = a->sk > 1 ? a->sk : 1;
   if (sk > 1 && (!a->sk_scratch || !a->sk_tickets || a->KT % sk != 0)) return dia_fail(DIA_E_ARG, "dia_gemm: split-K needs sk_scratch, sk_tickets and KT % sk == 0");
   if (sk > 1 && !a->nw) { const int ktl = a->KT / sk; nw = (ktl % 16 == 0 && ktl / 16 <= 4) ? 16 : ((ktl % 8 == 0) ? 8 : 4); }
-  if (a->M <= 4 && fast_epi && !a->act_f32) {      // (k_gemv_small stages the three planes; fp32 tiles go to the 16-row kernel)
+  const bool emits_ = a->epi == DIA_EPI_RESID_EMIT || a->epi == DIA_EPI_SWIGLU_EMIT;
+  const bool uni_f32 = k.a_f32 && (!emits_ || k.p_f32);          // fp32 tiles in, fp32 tiles out (or nothing emitted)
+  if (a->M <= 4 && fast_epi && (!a->act_f32 || uni_f32)) {       // (a mixed-format call goes on to the generic kernel)
     const int rs = a->M <= 2 ? 2 : 4;
     if (small_smem(nw, a->KT / sk, rs) <= 150 * 1024) {
       bool handled = false;
-      int rc = (rs == 2) ? launch_small_rs<2>(k, nw, sk, st, handled) : launch_small_rs<4>(k, nw, sk, st, handled);
+      int rc;
+      if (uni_f32) rc = (rs == 2) ? launch_small_rs<2, true>(k, nw, sk, st, handled) : launch_small_rs<4, true>(k, nw, sk, st, handled);
+      else rc = (rs == 2) ? launch_small_rs<2>(k, nw, sk, st, handled) : launch_small_rs<4>(k, nw, sk, st, handled);
       if (handled) return rc;
     }
   }

@@ -204,7 +204,7 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
 // spends 0.5 us of single-wave issue time (8 three-way bf16 splits per thread) at the very end of every launch.  Results are
 // bit-identical to run_epilogue: the strip's sum of squares is accumulated in the same order (columns 0..7 of each half in
 // sequence, rounded squares and plain adds, then half 0 + half 1), carried from lane to lane by DPP row shifts.
-template <int RS>
+template <int RS, bool PF32 = false>
 __device__ __forceinline__ void run_epilogue_rows(const GemmK& p, float v_tile, const float* inv_s, int tid, int strip,
                                                   float xpre1, float gpre1) {
   const int m = tid >> 4, c = tid & 15;
@@ -226,12 +226,16 @@ __device__ __forceinline__ void run_epilogue_rows(const GemmK& p, float v_tile, 
     int cc = n;
     if (p.cmap) cc = p.cmap[n];
     if (live && cc >= 0) {
-      __bf16 a, b, d;
-      split3(vg, a, b, d);
       const long off = plane_frag_off(m, cc & ~7, p.p_ktiles) + (cc & 7);
-      p.P[off] = *reinterpret_cast<bf16_raw*>(&a);
-      p.P[p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&b);
-      p.P[2 * p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&d);
+      if constexpr (PF32) {
+        reinterpret_cast<float*>(p.P)[off] = vg;        // fp32 tile: one 4-byte store instead of three 2-byte ones
+      } else {
+        __bf16 a, b, d;
+        split3(vg, a, b, d);
+        p.P[off] = *reinterpret_cast<bf16_raw*>(&a);
+        p.P[p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&b);
+        p.P[2 * p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&d);
+      }
     }
   } else if (p.epi == DIA_EPI_SWIGLU_EMIT) {    // columns 0..7 gate, 8..15 up
     const float up_raw = DIA_ROW_SHL(v_tile, 8);                        // lane c < 8 takes column c + 8
@@ -239,12 +243,16 @@ __device__ __forceinline__ void run_epilogue_rows(const GemmK& p, float v_tile, 
     const float inv = inv_s[m];
     const float g = v_tile * inv, u = up_raw * inv;
     const float v = (g / (1.0f + expf(-g))) * u;
-    __bf16 a, b, d;
-    split3(v, a, b, d);
     const long off = plane_frag_off(m, strip * 8, p.p_ktiles) + c;
-    p.P[off] = *reinterpret_cast<bf16_raw*>(&a);
-    p.P[p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&b);
-    p.P[2 * p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&d);
+    if constexpr (PF32) {
+      reinterpret_cast<float*>(p.P)[off] = v;
+    } else {
+      __bf16 a, b, d;
+      split3(v, a, b, d);
+      p.P[off] = *reinterpret_cast<bf16_raw*>(&a);
+      p.P[p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&b);
+      p.P[2 * p.p_plane_stride + off] = *reinterpret_cast<bf16_raw*>(&d);
+    }
   } else {                                      // DIA_EPI_SCALE_STORE
     if (!live) return;
     const int s_out = p.strip_map ? p.strip_map[strip] : strip;         // compacted output: whole heads dropped

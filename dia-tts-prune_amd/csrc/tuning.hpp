@@ -15,8 +15,8 @@ enum dia_tune_id {
   DIA_TUNE_WO_PAIR,            // wo_pair: 0 = no split-K 4 per m-tile at 17..128 rows
   DIA_TUNE_WO_NW,              // wo_nw / wo_spw: waves and strips per workgroup of wo
   DIA_TUNE_WO_SPW,
-  DIA_TUNE_ACT_F32,            // act_f32: 0 = the decode step keeps three bf16 activation planes at every batch size; 1 / unset =
-                               // fp32 activation tiles from 5 rows on (read by the host side when it builds a session)
+  DIA_TUNE_ACT_F32,            // act_f32: 0 = the decode step keeps three bf16 activation planes between its kernels; 1 / unset =
+                               // fp32 activation tiles (read by the host side when it builds a session)
   // ---- EXPERIMENTS=1 builds only
   DIA_TUNE_MLP_FUSE,           // mlp_fuse: 1 = wi + wo as one persistent launch at batch 1 (dia_mlp_fused)
   DIA_TUNE_TILE_V,             // tile_v: prefill tile kernel variant (0..5; 3 = wave-specialised default)

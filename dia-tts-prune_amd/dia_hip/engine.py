@@ -302,12 +302,12 @@ class DecodeSession:
         mt = self.rows_pad // 16
         self.xkt, self.akt, self.hkt = self.D // 32, max(d.gqa_query_heads, d.cross_query_heads) * HEAD_DIM // 32, self.F // 32
         self.x = z(self.rows_pad, self.D)
-        # activations between the kernels of a step: three bf16 planes (hi + mid + lo == fp32) up to 4 rows, where the GEMV stages
-        # them through LDS; from 5 rows on fp32 tiles in the same buffers (4 instead of 6 bytes per value: every workgroup of
-        # the 16-row GEMM pulls the whole activation matrix, 192 KB at batch 8, and splits the planes in registers — same
-        # arithmetic).  Tuning knob act_f32=0 keeps the planes.
+        # activations between the kernels of a step travel as fp32 tiles in these buffers (the fragment order of one plane, 4-byte
+        # values: 4 instead of the 6 bytes of three bf16 planes hi + mid + lo == fp32); every consumer splits the planes itself — the
+        # M <= 4 GEMV while staging its image through LDS, the 16-row GEMM in registers — same arithmetic bit for bit.
+        # Tuning knob act_f32=0 keeps the planes between the kernels.
         t_ = hb.get_tuning("act_f32")
-        self.act_f32 = int(self.R > 4 and t_ != 0)
+        self.act_f32 = int(t_ != 0)
         self.planes_x = z(3, mt, self.xkt, 64, 8, dt=torch.bfloat16)
         self.planes_a = z(3, mt, self.akt, 64, 8, dt=torch.bfloat16)
         self.planes_h = z(3, mt, self.hkt, 64, 8, dt=torch.bfloat16)

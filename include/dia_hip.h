@@ -129,9 +129,9 @@ typedef struct {
   /* fp32 ACTIVATION TILES: bit 0 = A is, bit 1 = P receives the fragment order of one plane ([mtile][ktile][lane][8]) with 4-byte
    * elements — 4 bytes per value instead of the 6 of three planes (a_plane_stride / p_plane_stride unused; a buffer sized for three
    * planes holds them).  The 5..128-row kernel is instantiated per format and splits each value into its planes in registers: same
-   * arithmetic bit for bit, a third less activation traffic per workgroup.  8-wave forms; mixed formats (one bit set) only where
-   * K / 32 / sk == 64; anything else runs the generic kernel.  Not available in the M <= 4 kernel (dia_gemm then takes the 16-row
-   * one) nor in the tiled prefill kernel. */
+   * arithmetic bit for bit, a third less activation traffic per workgroup.  Both bits (or bit 0 alone when nothing is emitted):
+   * the M <= 4 GEMV (splits while staging its image through LDS) and the 8-wave forms of the 5..128-row kernel; a mixed-format
+   * call runs the generic kernel.  Not available in the tiled prefill kernel. */
   int32_t act_f32;
   /* 0 / 1: W holds one bf16 tile set (exact for bf16-representable checkpoints).  3: W holds THREE tile sets back to back, the
    * hi / mid / lo bf16 planes of fp32 weights (hi + mid + lo == w exactly; plane stride = KT * nstrips * 512 elements): the
@@ -373,7 +373,7 @@ typedef struct {
   int64_t sk_scratch_floats;/* capacity of sk_scratch in floats (0 = the minimum above) */
   int32_t* mlp_barrier;     /* 2 int32 zeroed by the caller once: dia_mlp_fused's barrier words (NULL = never fuse) */
   int32_t act_f32;          /* 1: planes_x / planes_a / planes_h carry fp32 activation tiles (dia_gemm_args.act_f32); needs
-                             * more than 4 rows (B >= 3) and sample.embed.act_f32 == 1 */
+                             * sample.embed.act_f32 == 1 */
   int32_t w_planes;         /* 0 / 1, or 3: every weight pointer holds three bf16 planes of fp32 weights (dia_gemm_args.w_planes) */
   dia_sample_args sample;   /* sampler + FSM + embedding parameters */
 } dia_engine_desc;

@@ -889,7 +889,12 @@ def test_padded_o_rows_ignore_stale_planes(M):
     (16, 4096, 2048, "resid", 2, True), (40, 2048, 2048, "resid", 0, True), (128, 8192, 2048, "resid", 4, False),
     (16, 2048, 16384, "swiglu", 0, False), (24, 1024, 4096, "swiglu", 0, False),
     (16, 2048, 3072, "store", 0, False), (7, 1792, 1024, "store", 0, False), (64, 2048, 9264, "store", 0, False),
-    (16, 96, 80, "resid_generic", 0, False)])
+    (16, 96, 80, "resid_generic", 0, False),
+    # M <= 4: the LDS-staged GEMV (fp32 image split by the staging threads, one 4-byte store per emitted value)
+    (2, 2048, 2048, "resid", 0, False), (2, 2048, 2048, "resid", 0, True), (2, 2048, 3072, "store", 0, False),
+    (2, 2048, 16384, "swiglu", 0, False), (2, 8192, 2048, "resid", 2, False), (2, 2048, 9264, "store", 0, False),
+    (4, 2048, 2048, "resid", 0, False), (4, 8192, 2048, "resid", 2, True), (3, 1024, 4096, "swiglu", 0, False),
+    (1, 1792, 1024, "store", 0, False)])
 def test_act_f32_tiles_equal_planes_bitwise(M, K, N, epi, sk, mapped, fmt=3):
     """dia_gemm_args.act_f32 = 3: the A operand and the emitted activations are fp32 tiles (bit 0 / bit 1; mixed formats
     run the generic kernel, whose summation order differs from the 16-row kernel's)"""
