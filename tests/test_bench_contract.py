@@ -46,9 +46,12 @@ def test_traffic_file_names_the_kernels_of_the_bench_line():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["batch1"]
     d = _line("r02_bench_default.json")
     by = {x["kernel"]: x for x in d["roofline_by_kernel"]}
-    for name in ("k_gemv_small<8, 8, 2, false>", "k_gemv_small<16, 4, 2, true>", "k_gemv_small<8, 16, 2, false>"):
-        assert name in t and name in by
-        assert 0.95 <= t[name]["hbm_bytes_per_launch"] / by[name]["bytes_per_launch"] <= 1.15
+    gemvs = [n for n in by if n.startswith("k_gemv_small<")]           # (qkv/o/cq/co, wi, wo, logits: the weight streams of a batch-1 step)
+    assert len(gemvs) >= 3
+    for name in gemvs:
+        assert name in t, name
+        assert 0.95 <= t[name]["hbm_bytes_per_launch"] / by[name]["bytes_per_launch"] <= 1.15, name
+    assert d["roofline"]["traffic"] == t[d["roofline"]["kernel"]]["hbm_bytes_per_launch"]
 
 
 def test_other_config_lines():
