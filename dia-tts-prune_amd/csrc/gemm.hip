@@ -1140,11 +1140,6 @@ extern "C" int dia_has_experiments(void) {
 //   5..16 rows        k_gemm16       (register-resident A fragments)
 //   17..128 rows      k_gemm16 over gridDim.z m-tiles (weights shared through one XCD's L2)
 // Prefill (hundreds of packed rows): k_gemm_tile_ws (MFMA-bound).  Everything else: k_gemm (any shape).
-static inline bool uni_f32_early(const dia_gemm_args* a) {      // fp32 tiles in, fp32 tiles out (or nothing emitted)
-  const bool emits = a->epi == DIA_EPI_RESID_EMIT || a->epi == DIA_EPI_SWIGLU_EMIT;
-  return (a->act_f32 & 1) && (!emits || (a->act_f32 & 2));
-}
-
 extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   if (!a || !a->A || (!a->W && !a->sp_blocks)) return dia_fail(DIA_E_ARG, "dia_gemm: null argument");
   if (a->M <= 0 || a->KT <= 0 || a->nstrips <= 0) return dia_fail(DIA_E_ARG, "dia_gemm: empty problem");
@@ -1198,9 +1193,9 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   // The engine uses it for wo (K = 8192 over 128 strips): 2 at M <= 4, 4 at 5..16 rows and per m-tile above.
   const int sk = a->sk > 1 ? a->sk : 1;
   if (sk > 1 && (!a->sk_scratch || !a->sk_tickets || a->KT % sk != 0)) return dia_fail(DIA_E_ARG, "dia_gemm: split-K needs sk_scratch, sk_tickets and KT % sk == 0");
-  // (M <= 4 with the fp32 image: sixteen waves x 8 k-tiles beat eight x 16 on wo, 9.4 vs 10.0 us — half the loads per wave in flight
-  // before its first MFMA; with the three-plane image it was the other way round)
-  if (sk > 1 && !a->nw) { const int ktl = a->KT / sk; nw = (ktl % 16 == 0 && ktl / 16 <= ((a->M <= 4 && uni_f32_early(a)) ? 8 : 4)) ? 16 : ((ktl % 8 == 0) ? 8 : 4); }
+  // (M <= 4: sixteen waves x 8 k-tiles beat eight x 16 on wo, 9.4 vs 10.0 us with the fp32 image — half the loads per wave in
+  // flight before its first MFMA.  The same wave count for both activation formats: their results stay identical bit for bit)
+  if (sk > 1 && !a->nw) { const int ktl = a->KT / sk; nw = (ktl % 16 == 0 && ktl / 16 <= (a->M <= 4 ? 8 : 4)) ? 16 : ((ktl % 8 == 0) ? 8 : 4); }
   const bool emits_ = a->epi == DIA_EPI_RESID_EMIT || a->epi == DIA_EPI_SWIGLU_EMIT;
   const bool uni_f32 = k.a_f32 && (!emits_ || k.p_f32);          // fp32 tiles in, fp32 tiles out (or nothing emitted)
   if (a->M <= 4 && fast_epi && (!a->act_f32 || uni_f32)) {       // (a mixed-format call goes on to the generic kernel)
