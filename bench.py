@@ -9,7 +9,8 @@ Workload (BASELINE.json):
           The same run also measures, at 1024 steps each whatever --steps says, every other single-GPU
           configuration of BASELINE.json (`configs` object of the JSON line): batch 1 with fp32 K/V (the
           configuration that meets the 1e-3 logit parity bound), batch 8 mixed text lengths 32..512 (configs[2]),
-          and the 50 %-structured-pruned, compacted checkpoint at batch 8 and batch 1 (configs[3]).
+          the 50 %-structured-pruned, compacted checkpoint at batch 8 and batch 1 (configs[3]), and all 64
+          utterances of configs[4] on this one GPU (512 steps): the N = 1 point of the multi-GPU curve.
   N > 1   configs[4] — 64 utterances in all, 64/N per GPU (mixed lengths), weights broadcast once from rank 0.
 Synthetic seeded weights (no checkpoint exists offline).  Everything is resident in HBM before the timed
 region; the loop replays one hipGraph per step and never syncs with the host inside the region.
@@ -288,7 +289,8 @@ def main():
     if world > 1:
         workload = (f"Dia-1.6B{pruned_txt} bf16 weights, {args.kv} K/V, {world * batch} utterances sharded data-parallel over {world} GPUs "
                     f"({batch} per GPU, mixed text lengths 32..512), {K} decode steps, weights broadcast once from rank 0 "
-                    f"(one flat {w.flat.numel() / 1e9:.2f} GB buffer), no per-step collective")
+                    f"(one flat {w.flat.numel() / 1e9:.2f} GB buffer), no per-step collective; the N = 1 point of this curve is the "
+                    f"`configs.batch64_mixed_bf16kv` entry of the default single-GPU line (same 64 utterances on one GPU)")
     else:
         workload = (f"Dia-1.6B{pruned_txt} bf16 weights, {args.kv} K/V, batch {batch}, {K} decode steps, text bytes {m['text_bytes']}")
     workload += f", cfg 3.0 / T 1.3 / top-p 0.95 / top-k 35, hipGraph={use_graph}"
@@ -355,6 +357,10 @@ def main():
         cfgs["batch8_mixed_bf16kv"] = brief(measure(w, cfg, batch=8, kv="bf16", steps=cs, warmup=16),
                                             "BASELINE configs[2]: batch 8, text bytes 32..512 (sum 1664), bf16 K/V")
         cfgs["batch8_mixed_f32kv"] = brief(measure(w, cfg, batch=8, kv="f32", steps=cs, warmup=16), "batch 8 mixed, fp32 K/V (parity configuration)")
+        # the N = 1 point of BASELINE configs[4]'s scaling curve: all 64 utterances on this one GPU (what `--gpus N` shards 64/N per GPU)
+        cfgs["batch64_mixed_bf16kv"] = brief(measure(w, cfg, batch=TOTAL_UTTERANCES_MULTI_GPU, kv="bf16", steps=min(cs, 512), warmup=16),
+                                             "BASELINE configs[4] at N = 1: 64 utterances on one GPU (text bytes 32..512 x 8), bf16 K/V, 512 steps; "
+                                             "the `--gpus N` lines shard these 64 utterances 64/N per GPU")
         from dia_hip.pruning import structured_prune_state_dict
         psd, _ = structured_prune_state_dict(cfg, sd_gpu, amount=0.5, dim=0, n=2)
         wp = DeviceWeights(cfg, psd, dev)

@@ -252,10 +252,17 @@ extern "C" int dia_engine_create(const dia_engine_desc* d, void* stream, dia_eng
 
 extern "C" int dia_engine_destroy(dia_engine* e) {
   if (!e) return DIA_OK;
+  // replays may still be queued: the executable graph (and the kernarg blocks it owns) must outlive them
+  hipError_t he = hipSuccess;
+  if (e->stream) he = hipStreamSynchronize(e->stream);
+  if (e->side) { hipError_t h2 = hipStreamSynchronize(e->side); if (he == hipSuccess) he = h2; }
   if (e->exec) (void)hipGraphExecDestroy(e->exec);
   if (e->graph) (void)hipGraphDestroy(e->graph);
+  for (auto& ev : e->pf_ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : e->prof) if (ev) (void)hipEventDestroy(ev);
+  if (e->side) (void)hipStreamDestroy(e->side);
   delete e;
-  return DIA_OK;
+  return he == hipSuccess ? DIA_OK : dia_fail_hip(he, "dia_engine_destroy: hipStreamSynchronize");
 }
 
 extern "C" int dia_engine_decode(dia_engine* e, int n_steps, int use_graph) {
@@ -284,7 +291,7 @@ extern "C" int dia_engine_decode(dia_engine* e, int n_steps, int use_graph) {
       e->pf_w.push_back({d.w_logits, (long)d.kt_logits * d.ns_logits * 1024});
       e->pf_w.push_back({nullptr, 0});
       if (!e->side && hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) return dia_fail(DIA_E_HIP, "hipStreamCreate(side)");
-      e->pf_ev.resize(e->pf_w.size() + 2);
+      e->pf_ev.assign(e->pf_w.size() + 2, nullptr);
       for (auto& ev : e->pf_ev)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return dia_fail(DIA_E_HIP, "hipEventCreate(prefetch)");
     }

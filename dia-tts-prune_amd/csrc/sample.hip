@@ -475,8 +475,11 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
     // next-step embedding rows: outside the EOS countdown and the BOS window the token written is the one just drawn, so
     // this wave pulls its channel's row (one dword per 64-byte line) towards the L2 of this XCD while the other waves
     // finish and the state machine runs; embed_rows() below then finds it there instead of in HBM
-    const float* row = p.e.emb + ((long)c * p.e.V + choice) * p.e.D;
-    for (int o = lane * 16; o < p.e.D; o += 64 * 16) warm += row[o];
+    // (all-NaN scores leave the argmax sentinel 0x7fffffff in `choice`: no row to warm then, and no read outside the table)
+    if ((unsigned)choice < (unsigned)p.e.V) {
+      const float* row = p.e.emb + ((long)c * p.e.V + choice) * p.e.D;
+      for (int o = lane * 16; o < p.e.D; o += 64 * 16) warm += row[o];
+    }
   }
   __syncthreads();
 
@@ -509,7 +512,8 @@ __global__ __launch_bounds__(MAXC * 64) void k_sample(SampleK p) {
         if (eos_countdown == 0) { finished = 1; last = cur - 1; }                     // model.py:795-797 (break)
         else if (cur >= p.max_tokens - p.max_delay - 1 && !eos_detected) { eos_detected = 1; eos_countdown = p.max_delay; }
       }
-      if (ch) tok_next[lane] = tk;
+      // (the row that is embedded next stays inside the table even when all-NaN scores left the argmax sentinel in the token)
+      if (ch) tok_next[lane] = min(max(tk, 0), p.e.V - 1);
       if (!finished) {
         last = cur;                                                                    // dec_step += 1
         if (cur + 1 > p.max_tokens - 1) finished = 1;                                  // while dec_step < max_tokens-1

@@ -1,6 +1,7 @@
 #include "tuning.hpp"
 #include "errors.hpp"
 #include "../../include/dia_hip.h"
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -41,7 +42,12 @@ void dia_tuning_init_from_env() {
     if (end == std::string::npos) end = s.size();
     const std::string item = s.substr(pos, end - pos);
     const size_t eq = item.find('=');
-    if (eq != std::string::npos) (void)dia_set_tuning(item.substr(0, eq).c_str(), atoi(item.c_str() + eq + 1));
+    // a typo in an A/B sweep would silently measure the default: say so on stderr (the run goes on)
+    if (eq == std::string::npos) {
+      if (!item.empty()) fprintf(stderr, "dia_hip: DIA_TUNE item '%s' ignored (expected name=value)\n", item.c_str());
+    } else if (dia_set_tuning(item.substr(0, eq).c_str(), atoi(item.c_str() + eq + 1)) != DIA_OK) {
+      fprintf(stderr, "dia_hip: DIA_TUNE knob '%s' unknown, ignored\n", item.substr(0, eq).c_str());
+    }
     pos = end + 1;
   }
 }

@@ -224,13 +224,14 @@ class DeviceWeights:
         self.flat = flat
 
     @classmethod
-    def empty_like_config(cls, cfg: DiaConfig, device: torch.device) -> "DeviceWeights":
+    def empty_like_config(cls, cfg: DiaConfig, device: torch.device, weight_planes: int = 1) -> "DeviceWeights":
         """Same tensors, zero-filled: the receive side of the multi-GPU weight broadcast (dense layout;
         a compacted, i.e. structured-pruned, model has checkpoint-dependent shapes: every rank then
-        loads the checkpoint itself instead of receiving a broadcast)."""
+        loads the checkpoint itself instead of receiving a broadcast).  `weight_planes` must be the sender's
+        (dist.broadcast_weights checks it on every rank before the arena travels)."""
         from .weights import param_shapes
         sd = {k: torch.zeros(shp, dtype=torch.float32, device=device) for k, shp in param_shapes(cfg).items()}
-        return cls(cfg, sd, device, compact="off")
+        return cls(cfg, sd, device, compact="off", weight_planes=weight_planes)
 
     def prefill_weight_bytes(self) -> int:
         """bf16 bytes the prefill streams once per batch: the encoder and the cross K/V projections"""
@@ -475,9 +476,12 @@ class DecodeSession:
                  "dia_engine_create")
 
     def close(self):
+        """Tear the engine down: the stream is drained first (queued graph replays read the executable graph's own
+        argument blocks), then dia_engine_destroy releases the graph, its side stream and events."""
         if self._engine:
-            hb.lib().dia_engine_destroy(self._engine)
-            self._engine = C.c_void_p()
+            eng, self._engine = self._engine, C.c_void_p()
+            self.stream.synchronize()
+            hb.check(hb.lib().dia_engine_destroy(eng), "dia_engine_destroy")
 
     def __del__(self):
         try:
@@ -771,6 +775,7 @@ class DecodeSession:
             g.inv_d, g.eps = 1.0 / self.D, float(self.cfg.model.normalization_layer_epsilon)
             g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(self.planes_h), self.planes_h[0].numel(), self.hkt
             g.act_f32 = 3 * self.act_f32             # as in the step
+            g.w_planes = self.w.weight_planes
             args.append(g)
         for g in args:                                    # warm
             hb.check(L.dia_gemm(C.byref(g), st), "dia_gemm(wi)")
@@ -800,6 +805,7 @@ class DecodeSession:
             a.ssq_in, a.ssq_in_n, a.ssq_ld = hb.ptr(self.ssq), self.D // 16, self.rows_pad
             a.inv_d, a.eps = 1.0 / self.D, float(self.cfg.model.normalization_layer_epsilon)
             a.P, a.p_plane_stride, a.p_ktiles = hb.ptr(self.planes_h), self.planes_h[0].numel(), self.hkt
+            a.w_planes = self.w.weight_planes
             b = hb.GemmArgs()
             b.A, b.a_plane_stride, b.a_ktiles, b.M = hb.ptr(self.planes_h), self.planes_h[0].numel(), self.hkt, self.R
             b.W, b.KT, b.nstrips, b.epi = hb.ptr(DL["wo"].t), DL["wo"].kt, DL["wo"].ns, hb.EPI_RESID_EMIT
@@ -807,6 +813,7 @@ class DecodeSession:
             b.gnext = hb.ptr(self.w.dec_layers[i + 1]["g_sa"] if i + 1 < len(self.w.dec_layers) else self.w.dec_norm)
             b.P, b.p_plane_stride, b.p_ktiles, b.ssq_out = hb.ptr(self.planes_x), self.planes_x[0].numel(), self.xkt, hb.ptr(self.ssq)
             b.sk_scratch, b.sk_tickets, b.sk = hb.ptr(self.sk_scratch), hb.ptr(self.sk_tickets), 2
+            b.w_planes = self.w.weight_planes
             pairs.append((a, b))
         bar = hb.ptr(self.mlp_barrier)
         for a, b in pairs:

@@ -3,7 +3,7 @@
 #   scratch/profile_round.sh r02
 set -e
 #   scratch/profile_round.sh r02 pmc      (only the counter passes + traffic.json)
-R=${1:-r02}
+R=${1:-r03}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 if [ "$2" != "pmc" ]; then
@@ -22,11 +22,12 @@ for cfg in "1:" "8:--batch 8" "8p:--batch 8 --pruned 0.5"; do
 done
 fi
 cd /tmp && export TMPDIR=/tmp
-# (--preheat 0: the counter passes do not time anything, and rocprofv3 --pmc segfaults as soon as a second decode
-# session — a second captured graph — is built in the profiled process, whether or not the first was torn down)
+# PMC_PREHEAT: round 2 ran these passes with --preheat 0 because rocprofv3 --pmc died with SIGSEGV when the profiled process
+# built a second decode session; since round 3 the session is drained before its graph is destroyed (DecodeSession.close,
+# dia_engine_destroy) and the passes run with the default preheat unless PMC_PREHEAT says otherwise
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-steps 0 --profile-steps 0 --no-configs --preheat 0 > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-steps 0 --profile-steps 0 --no-configs ${PMC_PREHEAT:+--preheat $PMC_PREHEAT} > $O/${R}_pmc_$c.log 2>&1 || { echo "pmc $c pass FAILED (see ${R}_pmc_$c.log)"; tail -5 $O/${R}_pmc_$c.log; continue; }
   python3 - <<PY
 import csv, glob, collections
 f = glob.glob("/tmp/pmc_$c/*/*counter_collection.csv")[0]

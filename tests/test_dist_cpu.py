@@ -162,3 +162,62 @@ def test_gloo_world2_one_broadcast_and_sharded_decode():
         want = O.generate(sd, cfg, t, max_tokens=10, seed=100 + u, keep_logits=False).tokens
         for _, _, _, _, _, bufs in res:
             assert np.array_equal(bufs[u], want), u
+
+
+def _worker_edges(rank, world, port, q):
+    """gather with an empty shard and ragged [T, C]; a weight-arena mismatch must raise on EVERY rank (no rank is left
+    waiting in the broadcast)."""
+    sys.path.insert(0, os.path.join(ROOT, "dia-tts-prune_amd"))
+    import torch.distributed as dist
+    from dia_hip import config as C
+    from dia_hip import dist as D
+    from dia_hip.engine import DeviceWeights
+    from dia_hip.weights import synthetic_state_dict
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cpu = torch.device("cpu")
+    # one utterance over two ranks: rank 1 owns nothing and names the device itself
+    local = [torch.arange(6 * 9, dtype=torch.int32).reshape(6, 9)] if rank == 0 else []
+    got = D.gather_utterances(local, 1, world, rank, device=cpu)
+    ok_empty = len(got) == 1 and torch.equal(got[0], torch.arange(6 * 9, dtype=torch.int32).reshape(6, 9))
+    # three utterances with different row counts: buffers come back cut to what their owner sent
+    rows = {0: 4, 1: 7, 2: 5}
+    mine = D.shard_utterances(3, world, rank)
+    local = [torch.full((rows[u], 9), u, dtype=torch.int32) for u in mine]
+    got = D.gather_utterances(local, 3, world, rank)
+    ok_ragged = all(tuple(got[u].shape) == (rows[u], 9) and bool((got[u] == u).all()) for u in range(3))
+    # arena mismatch: rank 0 holds three weight planes, rank 1 one -> both raise before any broadcast
+    cfg = C.mid_config()                 # real head_dim (the device layouts are built for 128)
+    if rank == 0:
+        w = DeviceWeights(cfg, synthetic_state_dict(cfg, 3, 0.02), cpu, weight_planes=3)
+    else:
+        w = DeviceWeights.empty_like_config(cfg, cpu)
+    raised = False
+    try:
+        D.broadcast_weights(w, src=0)
+    except ValueError as e:
+        raised = "differ across ranks" in str(e)
+    # and the matching receiver goes through
+    w1 = DeviceWeights(cfg, synthetic_state_dict(cfg, 3, 0.02), cpu, weight_planes=3) if rank == 0 else \
+        DeviceWeights.empty_like_config(cfg, cpu, weight_planes=3)
+    n = D.broadcast_weights(w1, src=0)
+    q.put((rank, ok_empty, ok_ragged, raised, n == w1.flat.numel() and float(w1.flat.float().abs().sum()) > 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gather_edges_and_arena_mismatch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker_edges, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_empty, ok_ragged, raised, ok_bcast in res:
+        assert ok_empty and ok_ragged and raised and ok_bcast, (rank, ok_empty, ok_ragged, raised, ok_bcast)

@@ -127,7 +127,7 @@ def test_batched_equals_single(mid):
         assert out[b].last_step == r.last_step
 
 
-@pytest.mark.parametrize("B", [10, 20, 40])
+@pytest.mark.parametrize("B", [10, 20, 40, 64])
 def test_large_batches_vs_oracle(mid, B):
     """batch 9-64 per GPU (17..128 rows: the one-m-tile GEMM kernel over 2..8 m-tiles, wo split four ways per m-tile):
     every utterance of the batch == its own oracle run (three distinct runs, dealt round-robin)."""
@@ -741,3 +741,115 @@ def test_fp32_checkpoint_exact_planes_or_rounded_once(mid, capsys):
     for i, p_ in enumerate(r_round.preds):
         assert np.array_equal(res[0].preds[1 + i], p_), i
     assert e_raw <= 5e-2                                        # the cost of rounding the weights once (bf16: 8 significand bits)
+
+
+def test_full_size_batch64_vs_oracle(full):
+    """BASELINE configs[4] at N = 1: all 64 utterances on one GPU (128 rows = 8 m-tiles through every GEMM of the step,
+    the largest row count the engine runs), Dia-1.6B shapes, text lengths 32..512.  Two teacher-forced steps against the lean
+    oracle for the 8 distinct utterances, dealt round-robin over the 64 slots (state.py:83-84 hard-codes one CFG pair; this is
+    the generalisation the multi-GPU shards rely on); then graph replay == eager, bitwise, in the perf configuration."""
+    cfg, sd, w, _ = full
+    steps = 2
+    mt = steps + 1
+    B = 64
+    texts8 = mixed_texts(FULL_LENS, cfg)
+    seeds8 = [42 + b for b in range(8)]
+    runs = [oracle_run(cfg, sd, t, sd_, mt, max_steps=steps) for t, sd_ in zip(texts8, seeds8)]
+    texts = [texts8[b % 8] for b in range(B)]
+    logits, res = teacher_forced(w, cfg, texts, [runs[b % 8][0].tokens for b in range(B)],
+                                 [runs[b % 8][1][: mt - 1] for b in range(B)], mt)
+    worst = 0.0
+    for b in range(B):
+        r = runs[b % 8][0]
+        for i in range(len(r.logits)):
+            worst = max(worst, float(np.abs(logits[i][b] - r.logits[i]).max()))
+        for i, p in enumerate(r.preds):
+            assert np.array_equal(res[b].preds[1 + i], p), (b, i)
+    print(f"Dia-1.6B batch 64 mixed: {steps} teacher-forced steps, logits max-abs err {worst:.3e}")
+    assert worst <= LOGIT_TOL
+    ids = [encode_text(effective_text(t), cfg) for t in texts]
+    outs = []
+    for use_graph in (False, True):
+        s = DecodeSession(w, ids, kv_dtype="bf16", max_tokens=12, seeds=[42 + b for b in range(B)], ignore_eos=True)
+        s.prefill(); s.run(use_graph=use_graph)
+        outs.append((np.stack([r_.tokens for r_ in s.results()]), s.logits_host().copy()))
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # slots that hold the same utterance with the same seed-independent teacher inputs differ only by their noise: the
+    # first sampled row of slot b and slot b + 8 comes from identical logits
+    assert np.array_equal(outs[0][1][0], outs[0][1][8])
+
+
+def long_config():
+    """the mid fixture's model with Dia-1.6B's buffer lengths: text_length 1024 and an audio buffer that holds a 1024-step
+    decode (BASELINE configs[1] is 1024 steps; mid_config stops at 256 rows).  Same weight generator: no parameter
+    depends on the lengths."""
+    d = C.config_to_json_dict(C.mid_config())
+    d["data"]["text_length"] = 1024
+    d["data"]["audio_length"] = 1152
+    return C.config_from_json_dict(d)
+
+
+def test_long_horizon_1024_steps_vs_oracle():
+    """No end-to-end comparison crossed 256 decode steps (the mid fixture's audio_length).  Here: 1024 teacher-forced steps
+    (model.py:748-807) with fp32 K/V — logits within 1e-3 of the oracle at EVERY step, every sample identical — through the
+    key-split growth of the self-attention (split counts change at 256 / 512 / 768 ... keys), the slab merges with many
+    live slabs and 1024 text keys; a batch of three with text lengths {0, 300, 1024}; and the error growth of the bf16-K/V
+    perf configuration over the same 1024 steps (recorded, bounded loosely)."""
+    cfg = long_config()
+    dev = torch.device("cuda:0")
+    sd = synthetic_state_dict(cfg, seed=1234, std=0.02)
+    w = DeviceWeights(cfg, sd, dev)
+    dm = O.Dims.of(cfg)
+    steps = 1024
+    mt = steps + 1
+    torch.set_num_threads(cpu_threads())
+    texts = ["", mixed_texts([300], cfg)[0], mixed_texts([1024], cfg)[0]]
+    ids = [encode_text(effective_text(t), cfg) for t in texts]
+    assert [len(i) for i in ids] == [0, 300, 1024]
+    runs = []
+    for i, t in enumerate(texts):
+        nz = O.exp_noise(21 + i, mt - 1, dm.C, dm.tgt_vocab)
+        runs.append((O.generate(sd, cfg, t, max_tokens=mt, noise=nz, mirror=False, ignore_eos=True), nz))
+    assert all(len(r.logits) == steps for r, _ in runs)
+
+    def run(kv, sel):
+        s = DecodeSession(w, [ids[b] for b in sel], kv_dtype=kv, max_tokens=mt, noise=torch.stack([runs[b][1] for b in sel]),
+                          teacher_tokens=[runs[b][0].tokens for b in sel])
+        s.prefill()
+        errs = np.zeros((steps, len(sel)))
+        for i in range(steps):
+            s.decode(1, use_graph=False)
+            lg = s.logits_host()
+            for j, b in enumerate(sel):
+                errs[i, j] = float(np.abs(lg[j] - runs[b][0].logits[i]).max())
+        res = s.results(); s.close()
+        agree = np.array([[np.array_equal(res[j].preds[1 + i], runs[b][0].preds[i]) for j, b in enumerate(sel)] for i in range(steps)])
+        return errs, agree
+
+    # single utterance, the longest text: the 1024-step teacher-forced run of the verdict
+    errs, agree = run("f32", [2])
+    print(f"long horizon, fp32 K/V, text 1024: {steps} steps, logits max-abs err {errs.max():.3e} "
+          f"(steps 1-256 {errs[:256].max():.2e}, 257-512 {errs[256:512].max():.2e}, 513-768 {errs[512:768].max():.2e}, "
+          f"769-1024 {errs[768:].max():.2e}), samples identical {agree.mean():.4f}")
+    assert errs.max() <= LOGIT_TOL and agree.all()
+    # batch of three, text lengths 0 / 300 / 1024
+    errs3, agree3 = run("f32", [0, 1, 2])
+    print(f"long horizon, fp32 K/V, batch 3 (text 0 / 300 / 1024): logits max-abs err per utterance "
+          f"{[float(f'{e:.2e}') for e in errs3.max(axis=0)]}, samples identical {agree3.mean():.4f}")
+    assert errs3.max() <= LOGIT_TOL and agree3.all()
+    # bf16 K/V (perf configuration): error growth over the same steps
+    errb, agreeb = run("bf16", [2])
+    q = [float(errb[a:b].max()) for a, b in ((0, 256), (256, 512), (512, 768), (768, 1024))]
+    print(f"long horizon, bf16 K/V, text 1024: logits max-abs err by quarter {[float(f'{v:.2e}') for v in q]}, "
+          f"samples identical {agreeb.mean():.4f}")
+    assert errb.max() <= 5e-2 and agreeb.mean() >= 0.9
+    # free-running graph replay over the whole horizon, fp32 K/V: the token buffer of the oracle's own free run
+    nz, free_o = runs[2][1], runs[2][0]                        # (the oracle's run above WAS free running)
+    s = DecodeSession(w, [ids[2]], kv_dtype="f32", max_tokens=mt, noise=nz[None], ignore_eos=True)
+    s.prefill(); s.run(use_graph=True)
+    out = s.results()[0]; s.close()
+    same = (out.tokens[:mt] == free_o.tokens[:mt]).all(axis=1)
+    first_bad = int(np.argmin(same)) if not same.all() else mt
+    print(f"long horizon, free running, graph replay: token rows identical up to row {first_bad} of {mt}")
+    assert first_bad >= 256
