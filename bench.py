@@ -71,10 +71,26 @@ def launch_bytes(sess, w, n_keys: int):
     kv_self = 2 * sess.R * d.kv_heads * 128 * kvb * n_keys
     kv_cross = 2 * d.cross_query_heads * 128 * kvb * sum(sess.lens)
     out = []
-    for L in w.dec_layers:
-        out += [L["qkv"].nbytes, kv_self, L["o"].nbytes, L["cq"].nbytes, kv_cross, L["co"].nbytes, L["wi"].nbytes, L["wo"].nbytes]
+    if getattr(sess, "seg", False):        # persistent MLP segments: co, wi, wo and the NEXT layer's qkv are one launch
+        for i, L in enumerate(w.dec_layers):
+            if i == 0:
+                out.append(L["qkv"].nbytes)
+            out += [kv_self, L["o"].nbytes, L["cq"].nbytes, kv_cross, w.seg_layers[i].numel() * 2]
+    else:
+        for L in w.dec_layers:
+            out += [L["qkv"].nbytes, kv_self, L["o"].nbytes, L["cq"].nbytes, kv_cross, L["co"].nbytes, L["wi"].nbytes, L["wo"].nbytes]
     out += [w.logits.nbytes, 0]
     return out
+
+
+def launch_ops(sess, nl: int):
+    """op label of every launch of a step, in launch order"""
+    if getattr(sess, "seg", False):
+        ops = []
+        for i in range(nl):
+            ops += (["qkv"] if i == 0 else []) + ["attn_self", "o", "cq", "attn_cross", "seg_co_wi_wo_qkv" if i + 1 < nl else "seg_co_wi_wo"]
+        return ops + ["logits", "sample_fsm_embed"]
+    return [LAUNCH_NAMES[i % 8] for i in range(nl * 8)] + ["logits", "sample_fsm_embed"]
 
 
 def kernel_table(sess, w, reps: int, graph_step_us: float):
@@ -94,7 +110,7 @@ def kernel_table(sess, w, reps: int, graph_step_us: float):
     n_keys = int(sess.cur.max().item())
     byts = launch_bytes(sess, w, n_keys)
     nl = sess.cfg.model.decoder.n_layer
-    ops = [LAUNCH_NAMES[i % 8] for i in range(nl * 8)] + ["logits", "sample_fsm_embed"]
+    ops = launch_ops(sess, nl)
     kus = ms.mean(axis=0) * 1e3                          # per launch
     boundary = max(0.0, (graph_step_us - float(kus.sum())) / len(kus))
     tab = {}
@@ -190,6 +206,7 @@ def measure(w, cfg, *, batch, kv, steps, warmup, use_graph=True, seeds=None, dis
            "frames_per_s": round(batch * steps / elapsed, 2), "rtf_per_utterance": round(steps / elapsed / FRAME_RATE, 3),
            "decode_weight_bytes": int(w.decode_weight_bytes()),
            "activations": "fp32 tiles, planes split in registers (more than 4 rows)" if sess.act_f32 else "three bf16 planes (hi + mid + lo == fp32)",
+           "launches_per_step": sess.launches_per_step(), "persistent_segments": bool(getattr(sess, "seg", False)),
            "step_roofline": {"bytes_per_step": int(step_bytes), "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
            "prefill": prefill}

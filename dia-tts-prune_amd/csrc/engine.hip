@@ -21,6 +21,8 @@ struct dia_engine {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   int launches = 0;
+  bool seg = false;               // the step runs persistent MLP segments (dia_seg_mlp)
+  std::vector<const void*> seg_w;
   int mlp_fused = -1;             // -1 not tried yet, 1 the MLP runs as one fused launch, 0 two launches
   std::vector<hipEvent_t> prof;   // when non-empty: one event recorded after every launch (profile step)
   // weight prefetch beside the chain (graph mode): launch i+lookahead's weights are pulled into the
@@ -79,9 +81,11 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     if (two_tiles) { g.sk_scratch = d.sk_scratch; g.sk_tickets = d.sk_tickets; g.sk_scratch_floats = d.sk_scratch_floats; }
   };
 
+  const bool seg = e->seg;            // persistent MLP segments: co, wi, wo and the next layer's qkv in one launch
   for (int l = 0; l < d.n_layer; ++l) {
     const dia_dec_layer& L = e->layers[l];
     dia_gemm_args g = {};
+    if (!seg || l == 0) {
     // q/k/v projection of the pre-SA-normed row (layers.py:541, 273-275)
     g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
     g.W = L.w_qkv; g.KT = L.kt_qkv; g.nstrips = L.ns_qkv; g.epi = DIA_EPI_SCALE_STORE;
@@ -91,6 +95,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   g.act_f32 = F;            // reads x as fp32 tiles
   g.w_planes = d.w_planes;
   if ((rc = dia_gemm(&g, st))) return rc; mark(e, n++);
+    }
 
     dia_attn_args a = {};
     a.mode = DIA_ATTN_SELF; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.kv_heads; a.group = d.q_heads / d.kv_heads;
@@ -133,6 +138,16 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     a.act_f32 = F;
     if ((rc = dia_attn(&a, st))) return rc; mark(e, n++);
 
+    if (seg) {
+      dia_seg_args sa = {};
+      sa.a_in = (const float*)d.planes_a; sa.a_ktiles = akt; sa.M = R; sa.W = e->seg_w[l];
+      sa.has_qkv = l + 1 < d.n_layer; sa.nslots = dia_seg_slots(sa.has_qkv); sa.D = d.D; sa.F = d.F;
+      sa.x = d.x; sa.ldx = d.D; sa.g_mlp = L.g_mlp; sa.g_next = (l + 1 < d.n_layer) ? e->layers[l + 1].g_sa : d.g_final;
+      sa.qkv_out = d.qkv; sa.ldq = nqkv; sa.planes_x = (float*)d.planes_x; sa.xkt = xkt; sa.ssq = d.ssq; sa.ssq_ld = d.rows_pad;
+      sa.eps = d.eps; sa.ws = d.seg_ws;
+      if ((rc = dia_seg_mlp(&sa, st))) return rc; mark(e, n++);
+      continue;
+    }
     g = {};
     g.A = d.planes_a; g.a_plane_stride = as; g.a_ktiles = akt; g.M = R;
     g.W = L.w_co; g.KT = L.kt_co; g.nstrips = L.ns_co; g.epi = DIA_EPI_RESID_EMIT;
@@ -242,6 +257,21 @@ extern "C" int dia_engine_create(const dia_engine_desc* d, void* stream, dia_eng
   e->layers.assign(d->layers, d->layers + d->n_layer);
   e->d.layers = e->layers.data();
   e->stream = (hipStream_t)stream;
+  if (d->seg_w && d->seg_ws) {
+    const int nqkv = (d->q_heads + 2 * d->kv_heads) * 128;
+    if (2 * d->B > 4 || !d->act_f32 || d->w_planes > 1 || !dia_seg_supported(d->D, d->F, max(d->q_heads, d->cq_heads) * 128, nqkv) ||
+        d->cq_heads * 128 != 2048) {
+      delete e;
+      return dia_fail(DIA_E_ARG, "dia_engine_create: persistent segments need <= 4 rows, fp32 activation tiles, one weight plane, Dia-1.6B decoder shapes and 256 CUs");
+    }
+    for (int l = 0; l < d->n_layer; ++l) {
+      const dia_dec_layer& L = d->layers[l];
+      if (!d->seg_w[l] || L.cmap_mlp || L.cmap_next || L.smap_qkv) { delete e; return dia_fail(DIA_E_ARG, "dia_engine_create: persistent segments take dense (uncompacted) layers only"); }
+    }
+    e->seg_w.assign(d->seg_w, d->seg_w + d->n_layer);
+    e->d.seg_w = e->seg_w.data();
+    e->seg = true;
+  }
   // measured: 37 us fused vs 27 us as two launches (batch 1, full size) — the write-through stores of the hidden
   // planes are acknowledged late under the weight stream (up to 10 us), the barrier and the coherent re-read add
   // 3.5 us each.  Kept as an opt-in experiment.
@@ -334,7 +364,7 @@ __global__ void k_delay(long long ticks) {
 
 extern "C" int dia_engine_profile_step(dia_engine* e, float* ms, int cap) {
   if (!e || !ms) return dia_fail(DIA_E_ARG, "dia_engine_profile_step: null argument");
-  const int n = e->d.n_layer * 8 + 2;
+  const int n = dia_engine_launches_per_step(e);
   if (cap < n) return dia_fail(DIA_E_ARG, "dia_engine_profile_step: output array too small");
   e->prof.resize(n + 1);
   for (auto& ev : e->prof) {
@@ -365,7 +395,7 @@ extern "C" int dia_engine_profile_step(dia_engine* e, float* ms, int cap) {
 // events (launch.hpp): ms[i] = duration of the i-th kernel of the step, in launch order, as rocprofv3 would report it.
 extern "C" int dia_engine_time_step(dia_engine* e, float* ms, float* interval_ms, int cap) {
   if (!e || !ms) return dia_fail(DIA_E_ARG, "dia_engine_time_step: null argument");
-  const int n = e->d.n_layer * 8 + 2;
+  const int n = dia_engine_launches_per_step(e);
   if (cap < n) return dia_fail(DIA_E_ARG, "dia_engine_time_step: output array too small");
   dia_launch<k_delay>(dim3(1), dim3(64), 0, e->stream, 300000LL /* 100 MHz ticks = 3 ms */);
   dia_recorder_arm();
@@ -384,7 +414,7 @@ extern "C" int dia_engine_mlp_fused(const dia_engine* e) { return e && e->mlp_fu
 
 extern "C" int dia_engine_launches_per_step(const dia_engine* e) {
   if (!e) return dia_fail(DIA_E_ARG, "null engine");
-  return e->d.n_layer * 8 + 2;
+  return e->seg ? e->d.n_layer * 5 + 3 : e->d.n_layer * 8 + 2;
 }
 
 // ------------------------------------------------------------------------------------------------

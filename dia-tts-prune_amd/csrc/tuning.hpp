@@ -17,6 +17,11 @@ enum dia_tune_id {
   DIA_TUNE_WO_SPW,
   DIA_TUNE_ACT_F32,            // act_f32: 0 = the decode step keeps three bf16 activation planes between its kernels; 1 / unset =
                                // fp32 activation tiles (read by the host side when it builds a session)
+  DIA_TUNE_SEG,                // seg: 1 = batch 1-2 sessions run persistent MLP segments (dia_seg_mlp) when the model carries ring
+                               // arenas (DeviceWeights(seg="on")); unset / 0 = the eight-launch layer (read by the host side)
+  DIA_TUNE_SEG_NB,             // seg_nb: 16 KiB weight slots each streaming wave of dia_seg_mlp keeps in flight (1..3)
+  DIA_TUNE_SEG_DBG,            // seg_dbg: debug bits of dia_seg_mlp (1 = no weight loads: hand-off timing only, wrong results)
+  DIA_TUNE_SEG_SLEEP,          // seg_sleep: s_sleep units before the first loads of the waves that stream the later ops
   // ---- EXPERIMENTS=1 builds only
   DIA_TUNE_MLP_FUSE,           // mlp_fuse: 1 = wi + wo as one persistent launch at batch 1 (dia_mlp_fused)
   DIA_TUNE_TILE_V,             // tile_v: prefill tile kernel variant (0..5; 3 = wave-specialised default)

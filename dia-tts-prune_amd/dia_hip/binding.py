@@ -14,7 +14,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIA_HIP_LIB") or os.path.join(_HERE, "libdia_hip.so")   # override: experiments only
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 KV_F32, KV_BF16 = 0, 1
 EPI_SCALE_STORE, EPI_RESID_EMIT, EPI_SWIGLU_EMIT, EPI_CROSSKV = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
@@ -23,6 +23,7 @@ EXPORTS = (
     "dia_last_error", "dia_abi_version", "dia_device_count", "dia_set_tuning", "dia_get_tuning", "dia_has_experiments", "dia_gemm", "dia_gemm_timed", "dia_mlp_fused", "dia_mlp_fused_timed", "dia_engine_mlp_fused", "dia_attn", "dia_attn_scratch_floats", "dia_enc_kv_prep", "dia_enc_attn", "dia_dec_prefill_embed", "dia_dec_prefill_kv", "dia_dec_prefill_attn",
     "dia_embed_text", "dia_embed_tokens", "dia_sample", "dia_prefetch", "dia_engine_create", "dia_engine_destroy",
     "dia_engine_decode", "dia_engine_set_prefetch", "dia_engine_step_logits_only", "dia_engine_profile_step", "dia_engine_time_step", "dia_timed_kernel_name", "dia_engine_launches_per_step",
+    "dia_seg_mlp", "dia_seg_workspace_bytes", "dia_seg_workspace_control_bytes", "dia_seg_slots", "dia_seg_supported", "dia_seg_error",
 )
 
 
@@ -137,6 +138,18 @@ class EngineDesc(C.Structure):
         ("attn_scratch", C.c_void_p), ("attn_tickets", C.c_void_p), ("sk_scratch_floats", C.c_int64), ("mlp_barrier", C.c_void_p),
         ("act_f32", C.c_int32), ("w_planes", C.c_int32),
         ("sample", SampleArgs),
+        ("seg_w", C.POINTER(C.c_void_p)), ("seg_ws", C.c_void_p),
+    ]
+
+
+class SegArgs(C.Structure):
+    _fields_ = [
+        ("a_in", C.c_void_p), ("a_ktiles", C.c_int32), ("M", C.c_int32),
+        ("W", C.c_void_p), ("nslots", C.c_int32), ("has_qkv", C.c_int32), ("D", C.c_int32), ("F", C.c_int32),
+        ("x", C.c_void_p), ("ldx", C.c_int32), ("_pad0", C.c_int32),
+        ("g_mlp", C.c_void_p), ("g_next", C.c_void_p), ("qkv_out", C.c_void_p), ("ldq", C.c_int32), ("_pad1", C.c_int32),
+        ("planes_x", C.c_void_p), ("xkt", C.c_int32), ("_pad2", C.c_int32), ("ssq", C.c_void_p), ("ssq_ld", C.c_int32), ("eps", C.c_float),
+        ("ws", C.c_void_p), ("timeout_us", C.c_int32), ("_pad3", C.c_int32), ("stamps", C.c_void_p),
     ]
 
 
@@ -199,6 +212,12 @@ def lib() -> C.CDLL:
     L.dia_engine_time_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
     L.dia_timed_kernel_name.argtypes = [C.c_int]
     L.dia_timed_kernel_name.restype = C.c_char_p
+    L.dia_seg_mlp.argtypes = [C.POINTER(SegArgs), C.c_void_p]
+    L.dia_seg_workspace_bytes.restype = C.c_int64
+    L.dia_seg_workspace_control_bytes.restype = C.c_int64
+    L.dia_seg_slots.argtypes = [C.c_int]
+    L.dia_seg_supported.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.dia_seg_error.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

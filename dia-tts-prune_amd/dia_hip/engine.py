@@ -48,12 +48,16 @@ class DeviceWeights:
     """Checkpoint -> kernel layouts, resident in HBM (bf16 tiles; norms / embeddings fp32)."""
 
     def __init__(self, cfg: DiaConfig, sd: Dict[str, torch.Tensor], device: torch.device, compact: str = "auto",
-                 weight_planes: int = 1):
+                 weight_planes: int = 1, seg: str = "off"):
         """compact: "auto" = drop structure that a structured-pruned checkpoint zeroed (decoder only),
         "off" = keep every matrix at its checkpoint shape (zeros are streamed).
         weight_planes: 1 = every DenseGeneral kernel as ONE bf16 tile set (exact for bf16-representable checkpoints, the fast
         kernels); 3 = the hi / mid / lo bf16 planes of the fp32 weights (exact for any checkpoint, 3x the bytes, the generic
-        kernel: the parity configuration of a genuine fp32 checkpoint)."""
+        kernel: the parity configuration of a genuine fp32 checkpoint).
+        seg: "on" = a dense Dia-1.6B-shaped decoder on a GPU also carries the ring arenas of the persistent MLP segments
+        (layout.seg_ring; + 2.2 GB: co, wi, wo and the following layer's qkv once more, per CU in consumption order), which
+        batch 1-2 sessions then run instead of four launches per layer when the knob seg=1 is set.  EXPERIMENT, default "off":
+        measured 43 us per segment against 31 us for the four launches it replaces."""
         if weight_planes not in (1, 3):
             raise ValueError("weight_planes must be 1 or 3")
         self.weight_planes = weight_planes
@@ -181,6 +185,20 @@ class DeviceWeights:
                      wi=tile(lay.interleave_gate_up(wi3)), wo=tile(wo))
             self.dec_layers.append(L)
         self.cmap_first = i32(cpt._cmap(plans[0].keep_qkv)) if plans[0] is not None else None
+        self.seg_layers: List[torch.Tensor] = []
+        nqkv = (QH + 2 * KVH) * HEAD_DIM
+        if (seg == "on" and device.type == "cuda" and weight_planes == 1 and not self.compacted and D == 2048 and d.n_hidden == 8192
+                and QH * HEAD_DIM == 2048 and CH * HEAD_DIM == 2048 and nqkv == 3072):
+            for i in range(d.n_layer):
+                p = f"decoder.layers.{i}."
+                wi3 = dev(p + "mlp.wi_fused.weight")
+                qn = None
+                if i + 1 < d.n_layer:
+                    pn = f"decoder.layers.{i + 1}."
+                    qn = torch.cat([dev(pn + f"self_attention.{n_}_proj.weight").reshape(D, -1) for n_ in "qkv"], dim=1)
+                self.seg_layers.append(lay.seg_ring(dev(p + "cross_attention.o_proj.weight").reshape(-1, D), wi3[:, 0, :], wi3[:, 1, :],
+                                                    dev(p + "mlp.wo.weight"), qn))
+                del wi3, qn
         self.dec_norm = dev("decoder.norm.weight").contiguous()
         lw = dev("decoder.logits_dense.weight").reshape(D, -1)
         self.logits = tile(lw[keep_logits.to(device)] if logits_pruned else lw)
@@ -204,6 +222,7 @@ class DeviceWeights:
                     if L[k] is not None]
         out += [self.dec_norm, self.logits.t, self.cos_t, self.sin_t]
         out += [t for t in (self.cmap_first, self.enc_cmap_first) if t is not None]
+        out += self.seg_layers
         return out
 
     def pack_flat(self):
@@ -224,14 +243,14 @@ class DeviceWeights:
         self.flat = flat
 
     @classmethod
-    def empty_like_config(cls, cfg: DiaConfig, device: torch.device, weight_planes: int = 1) -> "DeviceWeights":
+    def empty_like_config(cls, cfg: DiaConfig, device: torch.device, weight_planes: int = 1, seg: str = "off") -> "DeviceWeights":
         """Same tensors, zero-filled: the receive side of the multi-GPU weight broadcast (dense layout;
         a compacted, i.e. structured-pruned, model has checkpoint-dependent shapes: every rank then
         loads the checkpoint itself instead of receiving a broadcast).  `weight_planes` must be the sender's
         (dist.broadcast_weights checks it on every rank before the arena travels)."""
         from .weights import param_shapes
         sd = {k: torch.zeros(shp, dtype=torch.float32, device=device) for k, shp in param_shapes(cfg).items()}
-        return cls(cfg, sd, device, compact="off", weight_planes=weight_planes)
+        return cls(cfg, sd, device, compact="off", weight_planes=weight_planes, seg=seg)
 
     def prefill_weight_bytes(self) -> int:
         """bf16 bytes the prefill streams once per batch: the encoder and the cross K/V projections"""
@@ -309,6 +328,11 @@ class DecodeSession:
         # Tuning knob act_f32=0 keeps the planes between the kernels.
         t_ = hb.get_tuning("act_f32")
         self.act_f32 = int(t_ != 0)
+        # persistent MLP segments (csrc/seg.hip, experiment): batch 1-2 on a model that carries the ring arenas, knob seg=1
+        self.seg = bool(self.R <= 4 and getattr(w, "seg_layers", None) and self.act_f32 and hb.get_tuning("seg") == 1)
+        self.seg_ws = None
+        if self.seg:
+            self.seg_ws = torch.zeros(int(hb.lib().dia_seg_workspace_bytes()), dtype=torch.uint8, device=dev)
         self.planes_x = z(3, mt, self.xkt, 64, 8, dt=torch.bfloat16)
         self.planes_a = z(3, mt, self.akt, 64, 8, dt=torch.bfloat16)
         self.planes_h = z(3, mt, self.hkt, 64, 8, dt=torch.bfloat16)
@@ -471,6 +495,10 @@ class DecodeSession:
         ed.act_f32 = self.act_f32
         ed.w_planes = w.weight_planes
         ed.sample = self._sample_args()
+        if self.seg:
+            self._seg_w = (C.c_void_p * n)(*[hb.ptr(t) for t in w.seg_layers])
+            ed.seg_w = C.cast(self._seg_w, C.POINTER(C.c_void_p))
+            ed.seg_ws = hb.ptr(self.seg_ws)
         self._desc = ed
         hb.check(hb.lib().dia_engine_create(C.byref(ed), C.c_void_p(self.stream.cuda_stream), C.byref(self._engine)),
                  "dia_engine_create")
@@ -745,6 +773,15 @@ class DecodeSession:
         self._issued += 1
         return np.array(buf[:], dtype=np.float64)
 
+    def launches_per_step(self) -> int:
+        return int(hb.lib().dia_engine_launches_per_step(self._engine))
+
+    def seg_error(self) -> int:
+        """0, or the code of a persistent-segment wait that timed out (synchronises the stream)"""
+        if not self.seg:
+            return 0
+        return int(hb.lib().dia_seg_error(hb.ptr(self.seg_ws), C.c_void_p(self.stream.cuda_stream)))
+
     def time_step(self) -> np.ndarray:
         """kernel durations (milliseconds, launch order) of one eager decode step, each kernel bracketed by its own
         dispatch-level start / stop events — what rocprofv3 --kernel-trace reports per kernel."""
@@ -846,6 +883,8 @@ class DecodeSession:
             remaining -= n
             self.ensure_noise(self._issued + min(poll, remaining))      # next chunk's noise is drawn while this one runs
             self.sync()
+            if self.seg and self.seg_error():
+                self.results()                               # raises with the give-up code
             if bool((self.fsm[:, 3] != 0).all().item()):
                 break
 
@@ -859,6 +898,11 @@ class DecodeSession:
         self.sync()
         if int(self.mlp_barrier[1].item()) != 0:
             raise hb.DiaHipError("fused MLP kernel: a workgroup gave up waiting at the grid barrier; results are invalid")
+        code = self.seg_error()
+        if code:
+            self.seg_ws[: int(hb.lib().dia_seg_workspace_control_bytes())].zero_()       # counters are inconsistent after a give-up
+            raise hb.DiaHipError(f"persistent MLP segment: an in-kernel wait timed out (code {code}: 1 x1, 2 hidden, 3 wo partials, "
+                                 f"4 x2) — were all 256 workgroups resident?  Results are invalid; set DIA_TUNE=seg=0 to run the launches")
         tok = self.tokens.cpu().numpy()
         prd = self.pred.cpu().numpy()
         fsm = self.fsm.cpu().numpy()

@@ -208,3 +208,47 @@ def sparse_untile(blocks: torch.Tensor, toff: torch.Tensor, ns: int, kt: int) ->
                 if masks[l] >> j & 1:
                     out[i, l, j] = vals[k]; k += 1
     return torch.from_numpy(out).view(torch.bfloat16).reshape(ns, kt, 64, 8)
+
+
+# ---- ring layout of the persistent MLP segment (csrc/seg.hip) ------------------------------------------------------
+SEG_CUS = 256            # one workgroup per CU of an MI355X
+SEG_K = 2048             # contraction length of one slot (16 tiles of 128 k x 4 columns)
+
+
+def _seg_slots(w2d: torch.Tensor) -> torch.Tensor:
+    """[2048, N] float (N % 4 == 0) -> bf16 [N/4, 16, 64, 8]: one 16 KiB slot per group of 4 columns.  Tile t, lane l,
+    element j = W[128 t + 32 ((l & 15) >> 2) + 8 (l >> 4) + j][4 group + (l & 3)] — four k-tiles of the four columns side
+    by side in the 16 B-operand columns of v_mfma_f32_16x16x32_bf16 (the matching A operand carries the rows of k-tile g in
+    rows 4g..4g+3, so the product is block diagonal)."""
+    K, N = w2d.shape
+    if K != SEG_K or N % 4:
+        raise ValueError("seg slots: K must be 2048 and N a multiple of 4")
+    lane = torch.arange(64, device=w2d.device)
+    t = torch.arange(16, device=w2d.device)
+    j = torch.arange(8, device=w2d.device)
+    k = (128 * t[:, None, None] + (32 * ((lane & 15) >> 2) + 8 * (lane >> 4))[None, :, None] + j[None, None, :])   # [16, 64, 8]
+    c = (lane & 3)[None, :, None].expand(16, 64, 8)
+    g = w2d.reshape(K, N // 4, 4)
+    out = g[k[None], torch.arange(N // 4, device=w2d.device)[:, None, None, None], c[None]]     # [N/4, 16, 64, 8]
+    return out.to(torch.bfloat16).contiguous()
+
+
+def seg_ring(co: torch.Tensor, wi_gate: torch.Tensor, wi_up: torch.Tensor, wo: torch.Tensor, qkv_next) -> torch.Tensor:
+    """The weights one persistent segment streams, per CU in consumption order: bf16 [256][slots][16][64][8].
+      co       [2048, 2048]  cross-attention o_proj ([heads*128, D]): CU c owns columns [8c, 8c+8)           -> 2 slots
+      wi_gate / wi_up [2048, 8192]: CU c owns hidden units [32c, 32c+32), gate slots then up slots          -> 16 slots
+      wo       [8192, 2048]: CU c owns K quarter c >> 6 of columns [32 (c & 63), +32)                        -> 8 slots
+      qkv_next [2048, 3072] or None (last layer): CU c owns columns [12c, 12c+12)                            -> 3 slots"""
+    D, F = co.shape[1], wi_gate.shape[1]
+    if co.shape != (SEG_K, 2048) or wi_gate.shape != (2048, 8192) or wi_up.shape != (2048, 8192) or wo.shape != (8192, 2048):
+        raise ValueError("seg_ring: built for the Dia-1.6B decoder shapes")
+    parts = [_seg_slots(co).reshape(SEG_CUS, 2, 16, 64, 8),
+             _seg_slots(wi_gate).reshape(SEG_CUS, 8, 16, 64, 8), _seg_slots(wi_up).reshape(SEG_CUS, 8, 16, 64, 8)]
+    # wo: [quarter q][K 2048][2048 columns] -> slots [q][512 groups] -> CU (q, c) takes groups [8c, 8c+8)
+    wo_s = torch.stack([_seg_slots(wo[q * SEG_K:(q + 1) * SEG_K]) for q in range(4)])            # [4, 512, 16, 64, 8]
+    parts.append(wo_s.reshape(4, 64, 8, 16, 64, 8).reshape(SEG_CUS, 8, 16, 64, 8))
+    if qkv_next is not None:
+        if qkv_next.shape != (2048, 3072):
+            raise ValueError("seg_ring: q/k/v projection must be [2048, 3072]")
+        parts.append(_seg_slots(qkv_next).reshape(SEG_CUS, 3, 16, 64, 8))
+    return torch.cat(parts, dim=1).contiguous()

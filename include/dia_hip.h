@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DIA_ABI_VERSION 5
+#define DIA_ABI_VERSION 6
 
 #define DIA_OK 0
 #define DIA_E_ARG (-1)     /* bad argument / unsupported shape */
@@ -320,6 +320,47 @@ int dia_sample(const dia_sample_args* a, void* stream);
  * consumer (weights of the next kernels of the decode chain); writes nothing. */
 int dia_prefetch(const void* ptr, int64_t nbytes, int nblocks, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Persistent MLP segment (csrc/seg.hip): cross o_proj -> wi_fused + SwiGLU -> wo (-> the NEXT layer's q/k/v projection)
+ * of one decoder layer in ONE launch, for M <= 4 rows (batch 1-2) of a dense Dia-1.6B-shaped decoder.  Replaces the
+ * launches co, wi, wo (and the following layer's qkv) of the step = reference DecoderLayer.forward layers.py:574-584
+ * (+ layers.py:541, 273-275 of the next layer).  256 workgroups, one per CU, all resident together; the weights come in
+ * the "ring layout" (dia_hip/layout.py seg_ring): per CU one contiguous run of 16 KiB slots in consumption order.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* a_in;        /* cross-attention output, fp32 activation tiles [ktile][64][8] of m-tile 0 (act_f32 format) */
+  int32_t a_ktiles;         /* its K/32 (= 64) */
+  int32_t M;                /* valid rows, 1..4 */
+  const void* W;            /* ring arena of this layer: bf16 [256][nslots][16][64][8] */
+  int32_t nslots;           /* dia_seg_slots(has_qkv): 29 with the next layer's q/k/v, 26 without */
+  int32_t has_qkv;
+  int32_t D, F;             /* 2048, 8192 (checked) */
+  float* x;                 /* residual stream [rows][ldx], updated in place */
+  int32_t ldx;
+  const float* g_mlp;       /* pre_mlp_norm weight [D] */
+  const float* g_next;      /* next consumer's norm weight [D]: the next layer's pre_sa_norm, or the final norm */
+  float* qkv_out;           /* [rows][ldq] q|k|v of the next layer (has_qkv) */
+  int32_t ldq;
+  float* planes_x;          /* fp32 activation tiles of x * g_next, as DIA_EPI_RESID_EMIT leaves them (launched consumers read these) */
+  int32_t xkt;
+  float* ssq;               /* [D/16][ssq_ld] strip sums of squares of x */
+  int32_t ssq_ld;
+  float eps;
+  void* ws;                 /* dia_seg_workspace_bytes() bytes; the first dia_seg_workspace_control_bytes() zeroed ONCE by the caller
+                             * (and again after any failed launch) */
+  int32_t timeout_us;       /* bound of every in-kernel wait; 0 = 20 ms */
+  void* stamps;             /* debug: int64 [256][16] wall-clock (100 MHz) stamps of every workgroup's sync wave; NULL = off */
+} dia_seg_args;
+int dia_seg_mlp(const dia_seg_args* a, void* stream);
+int64_t dia_seg_workspace_bytes(void);
+int64_t dia_seg_workspace_control_bytes(void);
+int32_t dia_seg_slots(int with_qkv);
+/* 1 when the shapes (D, F, attention width = heads * 128, q/k/v width) have a segment kernel and the device has the CUs */
+int dia_seg_supported(int D, int F, int attn_width, int nqkv);
+/* after a stream sync: 0, or the code of the in-kernel wait that timed out (1 x1, 2 hidden, 3 wo partials, 4 x2) */
+int dia_seg_error(const void* ws, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Engine: owns nothing but the launch sequence.  All memory is allocated by the caller.
  * ------------------------------------------------------------------------------------------------ */
@@ -376,6 +417,10 @@ typedef struct {
                              * sample.embed.act_f32 == 1 */
   int32_t w_planes;         /* 0 / 1, or 3: every weight pointer holds three bf16 planes of fp32 weights (dia_gemm_args.w_planes) */
   dia_sample_args sample;   /* sampler + FSM + embedding parameters */
+  /* persistent MLP segments (NULL / 0 = the eight-launch layer): host array [n_layer] of ring arenas (layer l's arena holds
+   * co, wi, wo of layer l and, for l + 1 < n_layer, qkv of layer l + 1), used when 2B <= 4 */
+  const void* const* seg_w;
+  void* seg_ws;             /* workspace of dia_seg_mlp */
 } dia_engine_desc;
 
 typedef struct dia_engine dia_engine;

@@ -34,9 +34,9 @@ def test_struct_sizes_match_header():
     prog = r'''
     #include <stdio.h>
     #include "dia_hip.h"
-    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(dia_gemm_args), sizeof(dia_attn_args),
+    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(dia_gemm_args), sizeof(dia_attn_args),
         sizeof(dia_embed_args), sizeof(dia_sample_args), sizeof(dia_dec_layer), sizeof(dia_engine_desc), sizeof(dia_enc_attn_args),
-        sizeof(dia_dec_prefill_args)); return 0; }
+        sizeof(dia_dec_prefill_args), sizeof(dia_seg_args)); return 0; }
     '''
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c")
@@ -44,7 +44,7 @@ def test_struct_sizes_match_header():
         exe = os.path.join(td, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    mine = [ctypes.sizeof(t) for t in (hb.GemmArgs, hb.AttnArgs, hb.EmbedArgs, hb.SampleArgs, hb.DecLayer, hb.EngineDesc, hb.EncAttnArgs, hb.DecPrefillArgs)]
+    mine = [ctypes.sizeof(t) for t in (hb.GemmArgs, hb.AttnArgs, hb.EmbedArgs, hb.SampleArgs, hb.DecLayer, hb.EngineDesc, hb.EncAttnArgs, hb.DecPrefillArgs, hb.SegArgs)]
     assert sizes == mine
 
 
@@ -57,5 +57,8 @@ def test_argument_validation_without_gpu():
     assert L.dia_attn(ctypes.byref(a), None) == -1
     s = hb.SampleArgs()
     assert L.dia_sample(ctypes.byref(s), None) == -1
+    sg = hb.SegArgs()
+    assert L.dia_seg_mlp(ctypes.byref(sg), None) == -1
+    assert L.dia_seg_workspace_bytes() > L.dia_seg_workspace_control_bytes() > 0
     with pytest.raises(hb.DiaHipError):
         hb.check(-1, "x")
