@@ -276,7 +276,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
   int sbuf = 0;
   auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
     const int next = strip + G;
-    if constexpr (MULTI) { if (next < p.nstrips) load_strip(bn, next); }     // next strip's weights stream while this one computes
+    // next strip's weights stream while this one computes.  UNCONDITIONAL (past the end: the last strip once more, an L2 hit that
+    // nobody reads): behind an `if` the wait before the first MFMA has to serve the path without the new loads too, the
+    // compiler then emits vmcnt(KPW - 1 - i) instead of vmcnt(2 KPW - 1 - i) and every MFMA waits for the load just issued
+    if constexpr (MULTI) load_strip(bn, DIA_PREFETCH_CLAMP(next, p.nstrips));
     f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
@@ -330,7 +333,17 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
 #define DIA_Z_TEMPORAL 1
 #endif
 constexpr bool ZTEMPORAL = DIA_Z_TEMPORAL != 0;
-template <int NW, int KPW, bool MULTI, bool MZ = false, bool AF32 = false, bool PF32 = false, bool PAIR = false>
+#ifndef DIA_ZR_RING3
+#define DIA_ZR_RING3 0
+#endif
+constexpr size_t g16_smem(int nw) { return sizeof(f32x4) * 2 * nw * 64 + 1536 + sizeof(float) * (2 * 16 * 17 + 16); }
+constexpr size_t g16_alds(int nw, int kpw) { return (size_t)2 * nw * kpw * 64 * 16; }     // mid + lo planes of every wave's A fragments
+// ALDS (17..128 rows, the z-form): only the hi plane of a wave's A fragments stays in registers; the mid and lo planes live in a
+// wave-private part of LDS (2 x 8 KiB per wave) and are re-read per strip (16 ds_read_b128 under the 24 MFMAs).  The 64 VGPRs
+// this frees let the z-form run the element-per-thread tail of the 16-row kernels (256 threads sum, scale and emit one tile
+// element each) instead of round 1's 32-thread tail, whose serial reduce + epilogue on ONE wave was what a strip cost
+// (1.7 us per strip at 128 rows against 0.32 us of MFMA time: in-kernel; a deeper weight ring alone changed nothing).
+template <int NW, int KPW, bool MULTI, bool MZ = false, bool AF32 = false, bool PF32 = false, bool PAIR = false, bool ALDS = false>
 __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
                                                     int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
   // (leading arguments = fields of p, preloaded into SGPRs: see k_gemv_small)
@@ -398,6 +411,16 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
       for (int pl = 0; pl < DIA_NPLANES; ++pl)
         a[i][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)(kt0 + i) * 64 + alane) * 8);
   }
+  bf16x8* my = reinterpret_cast<bf16x8*>(smem_raw + g16_smem(NW)) + (long)w * 2 * KPW * 64 + lane;     // ALDS: [plane - 1][i][lane]
+  if constexpr (ALDS) {
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) { my[i * 64] = a[i][1]; my[(KPW + i) * 64] = a[i][2]; }
+  }
+  // plane pl of the wave's i-th A fragment
+  auto afrag = [&](int i, int pl) -> bf16x8 {
+    if constexpr (ALDS) { if (pl > 0) return my[((pl - 1) * KPW + i) * 64]; }
+    return a[i][pl];
+  };
   // strip sums of squares: 8 threads per row
   const bool has_norm = p.ssq_in != nullptr;
   const int s_row = tid >> 3, s_part = tid & 7;
@@ -436,7 +459,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   // PAIR (host-selected instantiation): split-K with exactly two strips per workgroup, gridDim.y > 1 && 2 * gridDim.x == nstrips
   constexpr bool ZTAIL8 = MULTI && !MZ && !PAIR && KPW == 8 && AF32;
   constexpr bool pair = PAIR;
-  if constexpr (MZ || ZTAIL8) { if (resid && e_thread) load_resid8(blockIdx.x); }
+  constexpr bool ZT = (MZ && !ALDS) || ZTAIL8;       // the 32-thread tail
+  if constexpr (ZT) { if (resid && e_thread) load_resid8(blockIdx.x); }
   else { if (resid && r_thread) load_resid(blockIdx.x); }
   __builtin_amdgcn_sched_barrier(0);
   load_strip(b0, blockIdx.x);
@@ -457,7 +481,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   auto run_ztail = [&]() {
     auto body_z = [&](bf16x8* bc, bf16x8* bn, int strip) {
       const int next = strip + G;
-      if constexpr (MULTI) { if (next < p.nstrips) load_strip(bn, next); }
+      if constexpr (MULTI) load_strip(bn, DIA_PREFETCH_CLAMP(next, p.nstrips));     // unconditional: see k_gemv_small
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int i = 0; i < KPW; ++i)
@@ -481,8 +505,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
       body_z(b0, b1, blockIdx.x);
     }
   };
-  if constexpr (MZ) { run_ztail(); return; }
-  if constexpr (ZTAIL8) { run_ztail(); return; }
+  if constexpr (ZT) { run_ztail(); return; }
 
   // Cross-wave sum + epilogue, one tile element per thread (256 threads): the NW partial tiles go to LDS whole, a thread adds
   // the partials of ITS element in wave order (one barrier, double-buffered over the strips of the persistent form)
@@ -677,15 +700,16 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
     }
   }
   int sbuf = 0;
+  constexpr int DIST = (ALDS && DIA_ZR_RING3) ? 2 : 1;      // strips in flight ahead of the one being multiplied
   auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
     const int next = strip + G;
-    if constexpr (MULTI) { if (next < p.nstrips) load_strip(bn, next); }
+    if constexpr (MULTI) load_strip(bn, DIA_PREFETCH_CLAMP(strip + DIST * G, p.nstrips));       // unconditional: see k_gemv_small
     f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < KPW; ++i)
 #pragma unroll
       for (int pl = 0; pl < DIA_NPLANES; ++pl)
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][pl], bc[i], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag(i, pl), bc[i], acc[0], 0, 0, 0);
     STAMP(2);
     float v = 0.f;
     bool last_slice = true;
@@ -712,7 +736,17 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
     if (MULTI && next < p.nstrips && resid && r_thread) load_resid(next);
     STAMP(5);
   };
-  if constexpr (MULTI) {
+  if constexpr (MULTI && ALDS && DIA_ZR_RING3) {
+    // ring of three (measured, not used: 17 530 vs 17 862 frames/s at batch 64 — a strip is not latency-bound): the registers the mid / lo planes gave up hold a third strip, so TWO strips of weights are in flight
+    // behind the one being multiplied (a strip lasts 0.4-0.5 us of MFMA + tail, a load under the chip-wide stream 1.5-2 us)
+    bf16x8 b2[KPW];
+    load_strip(b1, DIA_PREFETCH_CLAMP(blockIdx.x + G, p.nstrips));
+    for (int strip = blockIdx.x; strip < p.nstrips; strip += 3 * G) {
+      body(b0, b2, strip);
+      if (strip + G < p.nstrips) body(b1, b0, strip + G);
+      if (strip + 2 * G < p.nstrips) body(b2, b1, strip + 2 * G);
+    }
+  } else if constexpr (MULTI) {
     for (int strip = blockIdx.x; strip < p.nstrips; strip += 2 * G) {
       body(b0, b1, strip);
       if (strip + G < p.nstrips) body(b1, b0, strip + G);
@@ -914,7 +948,7 @@ int launch_tile(const GemmK& k, hipStream_t st) {
 
 template <int NW, int KPW, bool AF32 = false, bool PF32 = false>
 int launch_g16(const GemmK& k, hipStream_t st) {
-  const size_t smem = sizeof(f32x4) * 2 * NW * 64 + 1536 + sizeof(float) * (2 * 16 * 17 + 16);
+  const size_t smem = g16_smem(NW);
   const int sk = k.KT / (NW * KPW);
   int spw = k.spw > 0 ? k.spw : (k.nstrips >= 1024 ? 4 : 1);
   const int mz = k.mz > 1 ? k.mz : 1;
@@ -932,6 +966,13 @@ int launch_g16(const GemmK& k, hipStream_t st) {
     if (spw > 1) {      // persistent multi-strip form, with or without split-K: A fragments loaded once per workgroup
       int gx = (k.nstrips + spw - 1) / spw;
       if (mz >= 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
+      if constexpr (NW == 8 && KPW == 8) {
+        if (mz > 1 && sk == 1 && dia_tune(DIA_TUNE_GEMM_ZR) != 0) {       // mid / lo planes of A in LDS: room for the element-per-thread tail
+          // (not with split-K: wo at 128 rows 59.9 vs 56.0 us — its hand-off drains the stream either way, the 32-thread tail is shorter there)
+          launch_small_kernel<k_gemm16<NW, KPW, true, true, AF32, PF32, false, true>>(dim3(gx, sk, mz), dim3(NW * 64), g16_smem(NW) + g16_alds(NW, KPW), st, k);
+          return dia_check_launch("k_gemm16");
+        }
+      }
       if (mz > 1) launch_small_kernel<k_gemm16<NW, KPW, true, true, AF32, PF32>>(dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
       else if (KPW == 8 && sk > 1 && 2 * gx == k.nstrips)      // strip pairs handed over together (wo at 5..16 rows)
         launch_small_kernel<k_gemm16<NW, (KPW == 8 ? 8 : KPW), true, false, AF32, PF32, KPW == 8>>(dim3(gx, sk), dim3(NW * 64), smem, st, k);
@@ -1115,6 +1156,8 @@ extern "C" int dia_dbg_stamps(long long* host, int n) {
 
 int dia_gemm_init() {
   int rc = 0;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile_ws<2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile_ws<2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile_ws<2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;

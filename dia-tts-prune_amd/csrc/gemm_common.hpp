@@ -22,6 +22,13 @@ namespace {
 #define DIA_WLOAD(ptr) __builtin_nontemporal_load(ptr)
 #endif
 
+// strip index of an unconditional prefetch (see k_gemv_small): past the end, the last strip once more
+#ifdef DIA_DBG_COND_PREFETCH
+#define DIA_PREFETCH_CLAMP(next, n) (next)
+#else
+#define DIA_PREFETCH_CLAMP(next, n) min((next), (n) - 1)
+#endif
+
 template <auto Kern, typename Arg>
 void launch_kernel(dim3 grid, dim3 block, size_t smem, hipStream_t st, const Arg& arg) {
   dia_launch<Kern>(grid, block, smem, st, arg);
