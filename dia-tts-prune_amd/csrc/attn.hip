@@ -579,15 +579,23 @@ __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
     __builtin_amdgcn_wave_barrier();     // pbuf is rewritten by the next granule
   };
 
-  // two granules per trip: the other register set is loading while one is consumed
-  for (int gi = g_first; gi < ngran; gi += 2 * gstride) {
-    const int g1 = gi + gstride, g2 = g1 + gstride;
+  // two granules per trip: the other register set is loading while one is consumed.  Steady state first — three granules
+  // known to exist, NO branch around a prefetch: behind an `if` the waits of the consuming MFMAs have to serve the path
+  // without the new loads too, the compiler then counts as if they had not been issued and every granule waited for the
+  // one requested just before it (no overlap at all; the GEMM kernels had the same: gemm.hip DIA_PREFETCH_CLAMP) — then a
+  // tail of at most two granules in the old, branchy form.
+  int gi = g_first;
+  for (; gi + 2 * gstride < ngran; gi += 2 * gstride) {
+    load_gran(fb, gi + gstride);
+    consume(fa, gi);
+    load_gran(fa, gi + 2 * gstride);
+    consume(fb, gi + gstride);
+  }
+  if (gi < ngran) {                // fa holds granule gi
+    const int g1 = gi + gstride;
     if (g1 < ngran) load_gran(fb, g1);
     consume(fa, gi);
-    if (g1 < ngran) {
-      if (g2 < ngran) load_gran(fa, g2);
-      consume(fb, g1);
-    }
+    if (g1 < ngran) consume(fb, g1);
   }
   ASTAMP(3);
   // per-wave partial -> LDS (lanes 0..15: dim 16*nb + lane, register g = head)

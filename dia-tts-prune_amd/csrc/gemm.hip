@@ -361,8 +361,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   // byte once and the second reader is served by that XCD's L2; everything row-indexed is shifted by 16 rows.
   // (a separate instantiation: the 16-row kernels stay exactly as they were — the extra prologue cost 2 % of the
   // batch-8 step)
+  int zrow0 = 0;                  // first row of this workgroup's m-tile (CROSSKV addresses rows of the packed batch globally)
   if constexpr (MZ) {
     const int z = blockIdx.z;
+    zrow0 = 16 * z;
     p.A += (long)z * p.a_ktiles * 512 * (AF32 ? 2 : 1);       // (bf16_raw pointer: an fp32 tile set is twice as wide)
     p.M = min(16, p.M - 16 * z);
     if (p.ssq_in) p.ssq_in += 16 * z;
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
       const bool last_slice = splitk_combine(p, tile, strip, tid, &sk_flag);      // workgroup-uniform; true without split-K
       if (e_thread) {
         const int n0 = strip * 16 + e_half * 8;
-        if (last_slice) run_epilogue(p, tile + e_r * 17, inv_s[e_r], e_r, n0, e_half, strip, e_live, xpre8, gpre8);
+        if (last_slice) run_epilogue(p, tile + e_r * 17, inv_s[e_r], (p.epi == DIA_EPI_CROSSKV ? zrow0 : 0) + e_r, n0, e_half, strip, e_live, xpre8, gpre8);
         if (MULTI && next < p.nstrips && resid) load_resid8(next);
       }
     };
@@ -967,7 +969,7 @@ int launch_g16(const GemmK& k, hipStream_t st) {
       int gx = (k.nstrips + spw - 1) / spw;
       if (mz >= 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
       if constexpr (NW == 8 && KPW == 8) {
-        if (mz > 1 && sk == 1 && dia_tune(DIA_TUNE_GEMM_ZR) != 0) {       // mid / lo planes of A in LDS: room for the element-per-thread tail
+        if (mz > 1 && sk == 1 && k.epi != DIA_EPI_CROSSKV && dia_tune(DIA_TUNE_GEMM_ZR) != 0) {       // mid / lo planes of A in LDS: room for the element-per-thread tail
           // (not with split-K: wo at 128 rows 59.9 vs 56.0 us — its hand-off drains the stream either way, the 32-thread tail is shorter there)
           launch_small_kernel<k_gemm16<NW, KPW, true, true, AF32, PF32, false, true>>(dim3(gx, sk, mz), dim3(NW * 64), g16_smem(NW) + g16_alds(NW, KPW), st, k);
           return dia_check_launch("k_gemm16");
@@ -1264,7 +1266,10 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   // weight stream through L2).  Split-K (a->sk > 1) needs scratch for every m-tile: mtiles * nstrips * sk * 256 floats,
   // mtiles * nstrips tickets.
   const int mz_max = dia_tune(DIA_TUNE_GEMM_MZ_MAX) >= 0 ? dia_tune(DIA_TUNE_GEMM_MZ_MAX) : 8;
-  if (mtiles >= 2 && mtiles <= mz_max && fast_epi && nw16 && (sk == 1 || a->sk_scratch_floats >= (int64_t)mtiles * a->nstrips * sk * 256)) {
+  // (the z-form's 32-thread tail runs the shared epilogue: the cross-K/V projections of a short prompt ride it too — the generic
+  // kernel they fell to spills and took 21-25 us per launch at 98 rows)
+  const bool z_epi = fast_epi || a->epi == DIA_EPI_CROSSKV;
+  if (mtiles >= 2 && mtiles <= mz_max && z_epi && nw16 && (sk == 1 || a->sk_scratch_floats >= (int64_t)mtiles * a->nstrips * sk * 256)) {
     bool handled = false;
     k.mz = mtiles;
     int rc = launch_g16_any(k, nw16, sk, st, handled);

@@ -575,7 +575,7 @@ class DecodeSession:
                                               ssq.data_ptr() + offs[b] * 4, Mp, hb.ptr(w.enc_cmap_first), st), "dia_embed_text")
 
                 def gemm(A, a_kt, W: TiledW, epi, *, M=Mp, a_ptr=None, ssq_ptr=None, ssq_in=False, out=None, ldo=0, gnext=None,
-                         P=None, p_kt=0, ssq_out=False, kv=None, strip_map=None, row_map=False, cmap=None):
+                         P=None, p_kt=0, ssq_out=False, kv=None, strip_map=None, row_map=False, cmap=None, sk=0):
                     g = hb.GemmArgs()
                     g.A, g.a_plane_stride, g.a_ktiles, g.M = (a_ptr if a_ptr is not None else hb.ptr(A)), A[0].numel(), a_kt, M
                     g.W, g.KT, g.nstrips, g.epi = hb.ptr(W.t), W.kt, W.ns, epi
@@ -598,6 +598,8 @@ class DecodeSession:
                         g.cos_t, g.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
                     if row_map:
                         g.row_b, g.seg_off = hb.ptr(row_b), hb.ptr(seg_off)
+                    if sk > 1:      # split-K over workgroups through the session's slab scratch (short prompts: the z-form needs K <= 2048 per workgroup)
+                        g.sk, g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = sk, hb.ptr(self.sk_scratch), hb.ptr(self.sk_tickets), self.sk_scratch.numel()
                     hb.check(L.dia_gemm(C.byref(g), st), "dia_gemm")
 
                 for i, EL in enumerate(w.enc_layers):
@@ -618,8 +620,15 @@ class DecodeSession:
                         raise hb.DiaHipError("encoder layer with every attention head pruned is not supported")
                     gemm(px, ekt, EL["wi"], hb.EPI_SWIGLU_EMIT, ssq_in=True, P=ph, p_kt=hkt)
                     gnext = w.enc_layers[i + 1]["g_sa"] if i + 1 < len(w.enc_layers) else w.enc_norm
+                    # 17..128 rows: wo (K = 4096) as two K halves per strip, so that it rides the z-form of the 16-row kernel instead
+                    # of the generic one (whose 4-m-tile form spills)
+                    wo_sk = 0
+                    kt_wo, ns_wo = EL["wo"].kt, EL["wo"].ns
+                    if (16 < Mp <= 128 and kt_wo % 16 == 0 and kt_wo // 2 <= 64 and w.weight_planes == 1 and EL["cmap_next"] is None
+                            and self.sk_scratch.numel() >= mt * ns_wo * 2 * 256 and self.sk_tickets.numel() >= mt * ns_wo):
+                        wo_sk = 2
                     gemm(ph, hkt, EL["wo"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=gnext, P=px, p_kt=ekt, ssq_out=True,
-                         cmap=EL["cmap_next"])
+                         cmap=EL["cmap_next"], sk=wo_sk)
                 # px now holds planes(x * encoder.norm.weight); ssq the row sums of squares of x
                 for i, DL in enumerate(w.dec_layers):
                     gemm(px, ekt, DL["ckv"], hb.EPI_CROSSKV, ssq_in=True,
