@@ -315,10 +315,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
     }
   };
   if constexpr (MULTI) {
-    for (int strip = blockIdx.x; strip < p.nstrips; strip += 2 * G) {
+    // strip PAIRS, then at most one more: with `if (second strip exists) body(b1, b0, ...)` inside the loop the compiler put an
+    // s_waitcnt vmcnt(0) at the loop header (the two ways into it leave different loads pending), i.e. the strip requested
+    // by the second body had to land before the next trip could start — found in the ISA, round 3
+    int strip = blockIdx.x;
+    for (; strip + G < p.nstrips; strip += 2 * G) {
       body(b0, b1, strip);
-      if (strip + G < p.nstrips) body(b1, b0, strip + G);
+      body(b1, b0, strip + G);
     }
+    if (strip < p.nstrips) body(b0, b1, strip);
   } else {
     body(b0, b1, blockIdx.x);
   }
@@ -499,10 +504,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
       }
     };
     if constexpr (MULTI) {
-      for (int strip = blockIdx.x; strip < p.nstrips; strip += 2 * G) {
+      int strip = blockIdx.x;                    // strip pairs, then at most one more (see k_gemv_small)
+      for (; strip + G < p.nstrips; strip += 2 * G) {
         body_z(b0, b1, strip);
-        if (strip + G < p.nstrips) body_z(b1, b0, strip + G);
+        body_z(b1, b0, strip + G);
       }
+      if (strip < p.nstrips) body_z(b0, b1, strip);
     } else {
       body_z(b0, b1, blockIdx.x);
     }
@@ -749,10 +756,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
       if (strip + 2 * G < p.nstrips) body(b2, b1, strip + 2 * G);
     }
   } else if constexpr (MULTI) {
-    for (int strip = blockIdx.x; strip < p.nstrips; strip += 2 * G) {
+    // strip PAIRS, then at most one more: with `if (second strip exists) body(b1, b0, ...)` inside the loop the compiler put an
+    // s_waitcnt vmcnt(0) at the loop header (the two ways into it leave different loads pending), i.e. the strip requested
+    // by the second body had to land before the next trip could start — found in the ISA, round 3
+    int strip = blockIdx.x;
+    for (; strip + G < p.nstrips; strip += 2 * G) {
       body(b0, b1, strip);
-      if (strip + G < p.nstrips) body(b1, b0, strip + G);
+      body(b1, b0, strip + G);
     }
+    if (strip < p.nstrips) body(b0, b1, strip);
   } else {
     body(b0, b1, blockIdx.x);
   }
@@ -968,7 +980,7 @@ int launch_g16(const GemmK& k, hipStream_t st) {
     if (spw > 1) {      // persistent multi-strip form, with or without split-K: A fragments loaded once per workgroup
       int gx = (k.nstrips + spw - 1) / spw;
       if (mz >= 2 && (gx * sk) % 8 != 0 && (gx + 7) / 8 * 8 <= k.nstrips) gx = (gx + 7) / 8 * 8;   // pairs on one XCD
-      if constexpr (NW == 8 && KPW == 8) {
+      if constexpr (NW == 8 && (KPW == 8 || KPW == 4)) {
         if (mz > 1 && sk == 1 && k.epi != DIA_EPI_CROSSKV && dia_tune(DIA_TUNE_GEMM_ZR) != 0) {       // mid / lo planes of A in LDS: room for the element-per-thread tail
           // (not with split-K: wo at 128 rows 59.9 vs 56.0 us — its hand-off drains the stream either way, the 32-thread tail is shorter there)
           launch_small_kernel<k_gemm16<NW, KPW, true, true, AF32, PF32, false, true>>(dim3(gx, sk, mz), dim3(NW * 64), g16_smem(NW) + g16_alds(NW, KPW), st, k);
@@ -1160,6 +1172,8 @@ int dia_gemm_init() {
   int rc = 0;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 4, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 4))) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 4, true, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 4))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile_ws<2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile_ws<2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tile_ws<2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gt_smem(2, 8)) != hipSuccess) rc = 1;
