@@ -8,7 +8,8 @@ Workload (BASELINE.json):
   N = 1   configs[1] — Dia-1.6B shapes, bf16 weights + bf16 K/V, batch 1, 1024 decode steps, README prompt.
           The same run also measures, at 1024 steps each whatever --steps says, every other single-GPU
           configuration of BASELINE.json (`configs` object of the JSON line): batch 1 with fp32 K/V (the
-          configuration that meets the 1e-3 logit parity bound), batch 8 mixed text lengths 32..512 (configs[2]),
+          configuration that meets the 1e-3 logit parity bound; also as two bf16 planes per value through the MFMA attention
+          kernel, "bf16x2"), batch 8 mixed text lengths 32..512 (configs[2]),
           the 50 %-structured-pruned, compacted checkpoint at batch 8 and batch 1 (configs[3]), and all 64
           utterances of configs[4] on this one GPU (512 steps): the N = 1 point of the multi-GPU curve.
   N > 1   configs[4] — 64 utterances in all, 64/N per GPU (mixed lengths), weights broadcast once from rank 0.
@@ -67,7 +68,7 @@ def launch_bytes(sess, w, n_keys: int):
     streams, the K/V an attention launch reads (self: both CFG rows of every utterance at length n_keys; cross: the cond
     rows' text keys), the logits head; the sampler reads the logits it is handed (L2-resident: 0)"""
     d = sess.cfg.model.decoder
-    kvb = 4 if sess.kv_code == 0 else 2
+    kvb = 2 if sess.kv_code == 1 else 4        # bf16: 2 bytes; fp32 and the two-plane bf16 caches: 4
     kv_self = 2 * sess.R * d.kv_heads * 128 * kvb * n_keys
     kv_cross = 2 * d.cross_query_heads * 128 * kvb * sum(sess.lens)
     out = []
@@ -225,7 +226,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: 1 on one GPU, 64/N on N GPUs)")
-    ap.add_argument("--kv", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--kv", default="bf16", choices=["bf16", "f32", "bf16x2"])
     ap.add_argument("--cpu-steps", type=int, default=40, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3, help="eager steps timed kernel by kernel for the roofline objects (0 = skip)")
@@ -371,9 +372,12 @@ def main():
             cfgs["batch1_bf16kv"] = brief(measure(w, cfg, batch=1, kv="bf16", steps=cs, warmup=16), "BASELINE configs[1]: batch 1, bf16 K/V")
         cfgs["batch1_f32kv"] = brief(measure(w, cfg, batch=1, kv="f32", steps=cs, warmup=16),
                                      "batch 1, fp32 K/V: the configuration whose logits meet 1e-3 against the fp32 reference path")
+        cfgs["batch1_bf16x2kv"] = brief(measure(w, cfg, batch=1, kv="bf16x2", steps=cs, warmup=16),
+                                        "batch 1, K/V as two bf16 planes (hi + lo, the bytes of fp32 caches) through the MFMA attention kernel: logits within 1e-3 too")
         cfgs["batch8_mixed_bf16kv"] = brief(measure(w, cfg, batch=8, kv="bf16", steps=cs, warmup=16),
                                             "BASELINE configs[2]: batch 8, text bytes 32..512 (sum 1664), bf16 K/V")
         cfgs["batch8_mixed_f32kv"] = brief(measure(w, cfg, batch=8, kv="f32", steps=cs, warmup=16), "batch 8 mixed, fp32 K/V (parity configuration)")
+        cfgs["batch8_mixed_bf16x2kv"] = brief(measure(w, cfg, batch=8, kv="bf16x2", steps=cs, warmup=16), "batch 8 mixed, two-plane bf16 K/V (MFMA attention, parity bound met)")
         # the N = 1 point of BASELINE configs[4]'s scaling curve: all 64 utterances on this one GPU (what `--gpus N` shards 64/N per GPU)
         cfgs["batch64_mixed_bf16kv"] = brief(measure(w, cfg, batch=TOTAL_UTTERANCES_MULTI_GPU, kv="bf16", steps=min(cs, 512), warmup=16),
                                              "BASELINE configs[4] at N = 1: 64 utterances on one GPU (text bytes 32..512 x 8), bf16 K/V, 512 steps; "

@@ -44,6 +44,7 @@ struct AttnK {
   int v_blocked;
   int gpw;          // MFMA kernel: granules a wave takes before the keys are split over another workgroup
   int act_f32;      // output as fp32 activation tiles instead of three bf16 planes
+  long kv_plane_stride;   // DIA_KV_BF16X2: elements between the hi and the lo plane of a cache (0 = one plane)
 };
 
 #ifdef DIA_DBG_STAMPS
@@ -394,16 +395,20 @@ __device__ __forceinline__ float row16_max(float v) {
 #else
 #define KVLOAD(ptr) (*(ptr))
 #endif
-template <int G>
-struct MfmaFrag { bf16x8 kb[2][4]; bf16x8 vb[8]; };
+// PL = bf16 planes per cache: 1 = bf16 K/V (the reference's GPU cache precision), 2 = DIA_KV_BF16X2 — every K / V value is kept
+// as hi + lo bf16 (16 significand bits, the bytes of an fp32 cache; written split by the producers), so the MFMA kernel
+// serves the parity configuration too: q (3 planes, exact) x K (2 planes) and p (2 planes) x V (2 planes), fp32 accumulation.
+// Two planes take the registers of both granule buffers: one granule at a time, no prefetch behind the one being consumed.
+template <int G, int PL>
+struct MfmaFrag { bf16x8 kb[PL][2][4]; bf16x8 vb[PL][8]; };
 
-template <int G>
+template <int G, int PL = 1>
 __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
   __shared__ __attribute__((aligned(16))) bf16_raw qf[4][DIA_NPLANES][G][4][8];   // q planes in A-fragment order
   __shared__ float part[NWV * G * HD];
   __shared__ float pm_s[NWV * 8], pl_s[NWV * 8];
   __shared__ __attribute__((aligned(16))) bf16_raw pbuf[NWV][2][16][32];
-  __shared__ __attribute__((aligned(16))) bf16_raw knew_s[HD], vnew_s[HD];
+  __shared__ __attribute__((aligned(16))) bf16_raw knew_s[PL][HD], vnew_s[PL][HD];
   __shared__ int last_s;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -451,26 +456,26 @@ __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
   const int klast = max(nkeys - 1, 0);
   const int gstride = NWV * nchunks;
   const int g_first = chunk * NWV + w;
-  auto load_gran = [&](MfmaFrag<G>& f, int gi) {
+  auto load_gran = [&](MfmaFrag<G, PL>& f, int gi) {
     const int key0 = gi << 5;
+    // all K planes first (S = Q.K^T runs before P.V, and vmcnt retires in order), then the V planes
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int pl = 0; pl < PL; ++pl) {
+      const bf16_raw* Kp = Kc + pl * p.kv_plane_stride;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#ifdef DIA_DBG_GRANMAJOR
-        f.kb[t][ks] = KVLOAD(reinterpret_cast<const bf16x8*>(reinterpret_cast<bf16_raw*>(p.kc) + (((long)gi * p.n_rows + kvrow) * p.n_kv_heads + kvh) * 4096 + (16 * t + arow) * HD + 32 * ks + 8 * akq));
-#else
-        f.kb[t][ks] = KVLOAD(reinterpret_cast<const bf16x8*>(Kc + (long)min(key0 + 16 * t + arow, klast) * HD + 32 * ks + 8 * akq));
-#endif
-#ifdef DIA_DBG_GRANMAJOR
-    const bf16_raw* Vblk = reinterpret_cast<bf16_raw*>(p.vc) + (((long)gi * p.n_rows + kvrow) * p.n_kv_heads + kvh) * 4096;
-#else
-    const bf16_raw* Vblk = Vc + (long)gi * HD * 32;
-#endif
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) f.vb[nb] = KVLOAD(reinterpret_cast<const bf16x8*>(Vblk + (long)(16 * nb + arow) * 32 + 8 * akq));
+        for (int ks = 0; ks < 4; ++ks)
+          f.kb[pl][t][ks] = KVLOAD(reinterpret_cast<const bf16x8*>(Kp + (long)min(key0 + 16 * t + arow, klast) * HD + 32 * ks + 8 * akq));
+    }
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl) {
+      const bf16_raw* Vblk = Vc + pl * p.kv_plane_stride + (long)gi * HD * 32;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) f.vb[pl][nb] = KVLOAD(reinterpret_cast<const bf16x8*>(Vblk + (long)(16 * nb + arow) * 32 + 8 * akq));
+    }
   };
-  MfmaFrag<G> fa, fb;
+  MfmaFrag<G, PL> fa, fb;        // (fb: one-plane caches only — two planes take the registers of both buffers)
   const bool have0 = g_first < ngran;
   load_gran(fa, have0 ? g_first : 0);          // idle waves re-read granule 0 (cache hit) and never use it
 
@@ -491,14 +496,22 @@ __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
   const int gslot = slot >> 5;
   const bool owner = slot >= 0 && (gslot % gstride) == g_first;      // wave-uniform
   if (owner) {
-    const float k1 = kx1 * rc - kx2 * rs, k2 = kx1 * rs + kx2 * rc;
-    const __bf16 k1b = (__bf16)k1, k2b = (__bf16)k2, v1b = (__bf16)vx1, v2b = (__bf16)vx2;
-    const bf16_raw k1r = *reinterpret_cast<const bf16_raw*>(&k1b), k2r = *reinterpret_cast<const bf16_raw*>(&k2b);
-    const bf16_raw v1r = *reinterpret_cast<const bf16_raw*>(&v1b), v2r = *reinterpret_cast<const bf16_raw*>(&v2b);
-    knew_s[lane] = k1r; knew_s[lane + 64] = k2r; vnew_s[lane] = v1r; vnew_s[lane + 64] = v2r;
-    Kc[(long)slot * HD + lane] = k1r; Kc[(long)slot * HD + lane + 64] = k2r;
-    bf16_raw* vdst = Vc + (long)gslot * HD * 32 + (slot & 31);
-    vdst[(long)lane * 32] = v1r; vdst[(long)(lane + 64) * 32] = v2r;
+    float kv4[4] = {kx1 * rc - kx2 * rs, kx1 * rs + kx2 * rc, vx1, vx2};      // k dims lane, lane + 64 (roped); v dims lane, lane + 64
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl) {       // plane pl = bf16 of what the planes before it left over (hi, then lo)
+      bf16_raw r4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 b = (__bf16)kv4[e];
+        r4[e] = *reinterpret_cast<const bf16_raw*>(&b);
+        kv4[e] -= (float)b;
+      }
+      knew_s[pl][lane] = r4[0]; knew_s[pl][lane + 64] = r4[1]; vnew_s[pl][lane] = r4[2]; vnew_s[pl][lane + 64] = r4[3];
+      bf16_raw* Kp = Kc + pl * p.kv_plane_stride;
+      Kp[(long)slot * HD + lane] = r4[0]; Kp[(long)slot * HD + lane + 64] = r4[1];
+      bf16_raw* vdst = Vc + pl * p.kv_plane_stride + (long)gslot * HD * 32 + (slot & 31);
+      vdst[(long)lane * 32] = r4[2]; vdst[(long)(lane + 64) * 32] = r4[3];
+    }
   }
   lds_barrier();     // q (and the owner's k/v copy) in LDS; global loads stay in flight
   ASTAMP(2);
@@ -513,24 +526,27 @@ __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) { mrun[g] = -INFINITY; lrun[g] = 0.f; }
 
-  auto consume = [&](MfmaFrag<G>& f, int gi) {
+  auto consume = [&](MfmaFrag<G, PL>& f, int gi) {
     const int key0 = gi << 5;
     if (owner && gi == gslot) {                 // the slot written this step: fragments from the LDS copy
       const int ts = (slot >> 4) & 1, ns = slot & 15, js = slot & 7, kqs = (slot & 31) >> 3;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kn = *reinterpret_cast<const bf16x8*>(&knew_s[32 * ks + 8 * akq]);
+      for (int pl = 0; pl < PL; ++pl) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          if (t == ts && arow == ns) f.kb[t][ks] = kn;
-      }
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kn = *reinterpret_cast<const bf16x8*>(&knew_s[pl][32 * ks + 8 * akq]);
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        const bf16_raw vr = vnew_s[16 * nb + arow];
-        const __bf16 vn = *reinterpret_cast<const __bf16*>(&vr);
+          for (int t = 0; t < 2; ++t)
+            if (t == ts && arow == ns) f.kb[pl][t][ks] = kn;
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j == js && akq == kqs) f.vb[nb][j] = vn;
+        for (int nb = 0; nb < 8; ++nb) {
+          const bf16_raw vr = vnew_s[pl][16 * nb + arow];
+          const __bf16 vn = *reinterpret_cast<const __bf16*>(&vr);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j == js && akq == kqs) f.vb[pl][nb][j] = vn;
+        }
       }
     }
     f32x4 S[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -539,9 +555,15 @@ __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
 #pragma unroll
       for (int pl = 0; pl < DIA_NPLANES; ++pl) {
         const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&qf[ks][pl][qrow_l][akq][0]);
+        // two K planes: q_hi.(K_hi + K_lo) + q_mid.K_hi — the products left out (q_mid.K_lo, q_lo.K) are below 2^-16 of the
+        // score, the resolution two K planes have anyway; one plane: all three q planes (exact q against bf16 K)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, f.kb[t][ks], S[t], 0, 0, 0);
+        for (int kp = 0; kp < PL; ++kp) {
+          if (PL == 2 && (pl + kp > 1)) continue;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, f.kb[kp][t][ks], S[t], 0, 0, 0);
+        }
       }
     // online softmax: in lanes 0..15, S[t][g] is the score of head g against key key0 + 16t + lane
     float alpha[4];
@@ -572,10 +594,12 @@ __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
     const bf16x8 pa0 = *reinterpret_cast<const bf16x8*>(&pbuf[w][0][arow][8 * akq]);
     const bf16x8 pa1 = *reinterpret_cast<const bf16x8*>(&pbuf[w][1][arow][8 * akq]);
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      O[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa0, f.vb[nb], O[nb], 0, 0, 0);
-      O[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa1, f.vb[nb], O[nb], 0, 0, 0);
-    }
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int vp = 0; vp < PL; ++vp) {
+        O[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa0, f.vb[vp][nb], O[nb], 0, 0, 0);
+        if (vp == 0) O[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa1, f.vb[vp][nb], O[nb], 0, 0, 0);     // (p_lo.V_lo: below 2^-16)
+      }
     __builtin_amdgcn_wave_barrier();     // pbuf is rewritten by the next granule
   };
 
@@ -584,18 +608,25 @@ __global__ __launch_bounds__(NT, 2) void k_attn_mfma(AttnK p) {
   // without the new loads too, the compiler then counts as if they had not been issued and every granule waited for the
   // one requested just before it (no overlap at all; the GEMM kernels had the same: gemm.hip DIA_PREFETCH_CLAMP) — then a
   // tail of at most two granules in the old, branchy form.
-  int gi = g_first;
-  for (; gi + 2 * gstride < ngran; gi += 2 * gstride) {
-    load_gran(fb, gi + gstride);
-    consume(fa, gi);
-    load_gran(fa, gi + 2 * gstride);
-    consume(fb, gi + gstride);
-  }
-  if (gi < ngran) {                // fa holds granule gi
-    const int g1 = gi + gstride;
-    if (g1 < ngran) load_gran(fb, g1);
-    consume(fa, gi);
-    if (g1 < ngran) consume(fb, g1);
+  if constexpr (PL == 1) {
+    int gi = g_first;
+    for (; gi + 2 * gstride < ngran; gi += 2 * gstride) {
+      load_gran(fb, gi + gstride);
+      consume(fa, gi);
+      load_gran(fa, gi + 2 * gstride);
+      consume(fb, gi + gstride);
+    }
+    if (gi < ngran) {                // fa holds granule gi
+      const int g1 = gi + gstride;
+      if (g1 < ngran) load_gran(fb, g1);
+      consume(fa, gi);
+      if (g1 < ngran) consume(fb, g1);
+    }
+  } else {
+    for (int gi = g_first; gi < ngran; gi += gstride) {
+      if (gi != g_first) load_gran(fa, gi);
+      consume(fa, gi);
+    }
   }
   ASTAMP(3);
   // per-wave partial -> LDS (lanes 0..15: dim 16*nb + lane, register g = head)
@@ -828,7 +859,8 @@ int launch_attn(const AttnK& k, int grid_y, int grid_z, hipStream_t st) {
 
 template <int G>
 int launch_attn_mfma(const AttnK& k, int grid_y, int grid_z, hipStream_t st) {
-  dia_launch<k_attn_mfma<G>>(dim3(k.n_kv_heads, grid_y, grid_z), dim3(NT), 0, st, k);
+  if (k.kv_plane_stride > 0) dia_launch<k_attn_mfma<G, 2>>(dim3(k.n_kv_heads, grid_y, grid_z), dim3(NT), 0, st, k);
+  else dia_launch<k_attn_mfma<G, 1>>(dim3(k.n_kv_heads, grid_y, grid_z), dim3(NT), 0, st, k);
   return dia_check_launch("k_attn_mfma");
 }
 
@@ -890,6 +922,12 @@ extern "C" int dia_attn(const dia_attn_args* a, void* stream) {
   if ((a->n_kv_heads * a->group * 128 + 31) / 32 > a->p_ktiles) return dia_fail(DIA_E_ARG, "dia_attn: output planes too narrow");
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = a->kv_dtype == DIA_KV_F32;
+  k.kv_plane_stride = 0;
+  if (a->kv_dtype == DIA_KV_BF16X2) {
+    if (!a->v_blocked || a->kv_plane_stride <= 0 || a->kv_plane_stride % 8 != 0)
+      return dia_fail(DIA_E_ARG, "dia_attn: two-plane bf16 K/V needs the blocked V layout and the plane stride of the caches");
+    k.kv_plane_stride = a->kv_plane_stride;
+  }
   if (a->v_blocked) {      // bf16 caches with the blocked V layout: MFMA kernel
     if (f32 || a->mode == DIA_ATTN_ENC || a->kv_cap % 32 != 0) return dia_fail(DIA_E_ARG, "dia_attn: v_blocked needs bf16 K/V, SELF/CROSS mode and kv_cap % 32 == 0");
     if (a->mode == DIA_ATTN_SELF && !a->cur) return dia_fail(DIA_E_ARG, "dia_attn: SELF needs cur");

@@ -101,7 +101,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     a.mode = DIA_ATTN_SELF; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.kv_heads; a.group = d.q_heads / d.kv_heads;
     a.n_rows = R; a.kv_cap = d.T; a.q = d.qkv; a.ldq = nqkv; a.q_off = 0; a.k_off = d.q_heads * 128;
     a.v_off = (d.q_heads + d.kv_heads) * 128; a.kc = L.k_self; a.vc = L.v_self; a.cur = d.sample.cur;
-    a.head_map = L.hmap_self; a.v_blocked = d.v_blocked; a.rope_rows = d.T + 1;
+    a.head_map = L.hmap_self; a.v_blocked = d.v_blocked; a.rope_rows = d.T + 1; a.kv_plane_stride = d.kv_plane_self;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
     a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
     a.act_f32 = F;
@@ -133,6 +133,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     a.mode = DIA_ATTN_CROSS; a.kv_dtype = d.kv_dtype; a.n_kv_heads = d.cq_heads; a.group = 1;
     a.n_rows = d.B; a.kv_cap = d.S; a.q = d.qc; a.ldq = d.cq_heads * 128; a.q_off = 0;
     a.kc = L.k_cross; a.vc = L.v_cross; a.cur = d.sample.cur; a.len = d.text_len; a.head_map = L.hmap_cross; a.v_blocked = d.v_blocked;
+    a.kv_plane_stride = d.kv_plane_cross;
     a.cos_t = d.cos_t; a.sin_t = d.sin_t; a.P = d.planes_a; a.p_plane_stride = as; a.p_ktiles = akt;
     a.scratch = d.attn_scratch; a.tickets = d.attn_tickets;
     a.act_f32 = F;

@@ -58,6 +58,7 @@ struct GemmK {
   const unsigned char* sp_blocks; const unsigned int* sp_toff;   // zero-skipping weight stream (k_gemv_sparse)
   int mz;                                  // host side only: m-tiles a k_gemm16 launch covers through gridDim.z (0/1 = one)
   int a_f32, p_f32;                        // A / P are fp32 activation tiles (common.hpp) instead of three bf16 planes
+  long kv_plane_stride;                    // CROSSKV, DIA_KV_BF16X2
   int w_planes; long w_plane_stride;       // k_gemm only: hi / mid / lo planes of fp32 weights, one tile set each
 };
 
@@ -89,9 +90,13 @@ void launch_small_kernel(dim3 grid, dim3 block, size_t smem, hipStream_t st, con
   dia_launch<Kern>(grid, block, smem, st, k.A, k.a_plane_stride, k.W, k.KT, k.M, k.epi, k.nstrips, k.out, k.ldo, k.gnext, k);
 }
 
-__device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v) {
+__device__ __forceinline__ void kv_store(void* base, int dtype, long idx, float v, long plane_stride = 0) {
   if (dtype == DIA_KV_F32) reinterpret_cast<float*>(base)[idx] = v;
-  else KVElem<bf16_raw>::store(reinterpret_cast<bf16_raw*>(base) + idx, v);
+  else if (dtype == DIA_KV_BF16X2) {      // hi + lo bf16 planes (16 significand bits)
+    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+    reinterpret_cast<bf16_raw*>(base)[idx] = *reinterpret_cast<const bf16_raw*>(&hi);
+    reinterpret_cast<bf16_raw*>(base)[idx + plane_stride] = *reinterpret_cast<const bf16_raw*>(&lo);
+  } else KVElem<bf16_raw>::store(reinterpret_cast<bf16_raw*>(base) + idx, v);
 }
 
 // Everything the epilogue needs from memory is requested early, behind the weight loads, so that its
@@ -183,8 +188,8 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
         const int i = i0 + t;
         const float x1 = trow[half * 8 + 2 * t] * inv, x2 = trow[half * 8 + 2 * t + 1] * inv;
         const float c = p.cos_t[(long)m * 64 + i], s = p.sin_t[(long)m * 64 + i];
-        kv_store(p.kc, p.kv_dtype, base + i, x1 * c - x2 * s);
-        kv_store(p.kc, p.kv_dtype, base + i + 64, x1 * s + x2 * c);
+        kv_store(p.kc, p.kv_dtype, base + i, x1 * c - x2 * s, p.kv_plane_stride);
+        kv_store(p.kc, p.kv_dtype, base + i + 64, x1 * s + x2 * c, p.kv_plane_stride);
       }
     } else {
       const int sv = strip - nk, head = sv >> 3, d0 = (sv & 7) * 16 + half * 8;
@@ -192,11 +197,11 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
         const long hb = ((long)kvb * p.kv_heads + head) * p.kv_cap * 128;
         const long blk = hb + (long)(m >> 5) * 128 * 32 + (m & 31);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) kv_store(p.vc, p.kv_dtype, blk + (long)(d0 + j) * 32, trow[half * 8 + j] * inv);
+        for (int j = 0; j < 8; ++j) kv_store(p.vc, p.kv_dtype, blk + (long)(d0 + j) * 32, trow[half * 8 + j] * inv, p.kv_plane_stride);
       } else {
         const long base = (((long)kvb * p.kv_heads + head) * p.kv_cap + m) * 128 + d0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) kv_store(p.vc, p.kv_dtype, base + j, trow[half * 8 + j] * inv);
+        for (int j = 0; j < 8; ++j) kv_store(p.vc, p.kv_dtype, base + j, trow[half * 8 + j] * inv, p.kv_plane_stride);
       }
     }
   }
@@ -360,6 +365,7 @@ inline int fill_gemmk(const dia_gemm_args* a, GemmK& k) {
   k.sp_blocks = (const unsigned char*)a->sp_blocks; k.sp_toff = (const unsigned int*)a->sp_toff;
   k.mz = 0;
   k.a_f32 = a->act_f32 & 1; k.p_f32 = (a->act_f32 >> 1) & 1;
+  k.kv_plane_stride = a->kv_plane_stride;
   k.w_planes = a->w_planes > 1 ? a->w_planes : 1; k.w_plane_stride = (long)a->KT * a->nstrips * 512;
   return DIA_OK;
 }

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIA_HIP_LIB") or os.path.join(_HERE, "libdia_hip.so")   # override: experiments only
 
 ABI_VERSION = 6
-KV_F32, KV_BF16 = 0, 1
+KV_F32, KV_BF16, KV_BF16X2 = 0, 1, 2
 EPI_SCALE_STORE, EPI_RESID_EMIT, EPI_SWIGLU_EMIT, EPI_CROSSKV = 0, 1, 2, 3
 ATTN_SELF, ATTN_CROSS, ATTN_ENC = 0, 1, 2
 
@@ -45,7 +45,7 @@ class GemmArgs(C.Structure):
         ("sk_scratch", C.c_void_p), ("sk_tickets", C.c_void_p), ("sk", C.c_int32), ("kv_vblocked", C.c_int32),
         ("row_b", C.c_void_p), ("seg_off", C.c_void_p), ("sk_scratch_floats", C.c_int64),
         ("sp_blocks", C.c_void_p), ("sp_toff", C.c_void_p),
-        ("act_f32", C.c_int32), ("w_planes", C.c_int32),
+        ("act_f32", C.c_int32), ("w_planes", C.c_int32), ("kv_plane_stride", C.c_int64),
     ]
 
 
@@ -58,7 +58,7 @@ class AttnArgs(C.Structure):
         ("enc_len", C.c_int32), ("rope_rows", C.c_int32), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p),
         ("P", C.c_void_p), ("p_plane_stride", C.c_int64), ("p_ktiles", C.c_int32), ("_pad1", C.c_int32),
         ("scratch", C.c_void_p), ("tickets", C.c_void_p), ("head_map", C.c_void_p),
-        ("v_blocked", C.c_int32), ("act_f32", C.c_int32),
+        ("v_blocked", C.c_int32), ("act_f32", C.c_int32), ("kv_plane_stride", C.c_int64),
     ]
 
 
@@ -139,6 +139,7 @@ class EngineDesc(C.Structure):
         ("act_f32", C.c_int32), ("w_planes", C.c_int32),
         ("sample", SampleArgs),
         ("seg_w", C.POINTER(C.c_void_p)), ("seg_ws", C.c_void_p),
+        ("kv_plane_self", C.c_int64), ("kv_plane_cross", C.c_int64),
     ]
 
 

@@ -303,10 +303,15 @@ class DecodeSession:
         self.max_tokens = self.T if max_tokens is None else int(max_tokens)
         if not (2 <= self.max_tokens <= self.T):
             raise ValueError(f"max_tokens must be in [2, {self.T}]")
-        self.kv_code = {"f32": hb.KV_F32, "float32": hb.KV_F32, "bf16": hb.KV_BF16, "bfloat16": hb.KV_BF16}[kv_dtype]
+        # "bf16x2": every K / V value as hi + lo bf16 in two planes of the bf16 layouts (16 significand bits, the bytes of the fp32
+        # caches): the MFMA attention kernel with logits inside the 1e-3 parity bound
+        self.kv_code = {"f32": hb.KV_F32, "float32": hb.KV_F32, "bf16": hb.KV_BF16, "bfloat16": hb.KV_BF16, "bf16x2": hb.KV_BF16X2}[kv_dtype]
+        if self.kv_code == hb.KV_BF16X2 and attention == "valu":
+            raise ValueError("kv_dtype 'bf16x2' is served by the MFMA attention kernel only")
         # bf16 caches keep V blocked as [key/32][128][32] for the MFMA attention kernel
-        self.v_blocked = int(self.kv_code == hb.KV_BF16 and attention != "valu")
+        self.v_blocked = int(self.kv_code in (hb.KV_BF16, hb.KV_BF16X2) and attention != "valu")
         kvt = torch.float32 if self.kv_code == hb.KV_F32 else torch.bfloat16
+        self.kv_planes = 2 if self.kv_code == hb.KV_BF16X2 else 1
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.lens = [int(len(t)) for t in text_ids]
         self.S = s_cap if s_cap is not None else max(32, _ceil(max(self.lens + [1]), 32))
@@ -342,10 +347,13 @@ class DecodeSession:
         self.qc = z(self.rows_pad, d.cross_query_heads * HEAD_DIM)
         self.ld_logits = w.logits.ns * 16
         self.logits = z(self.rows_pad, self.ld_logits)
-        self.k_self = [z(self.R, d.kv_heads, self.T, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
-        self.v_self = [z(self.R, d.kv_heads, self.T, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
-        self.k_cross = [z(B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
-        self.v_cross = [z(B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
+        pl = (self.kv_planes,) if self.kv_planes > 1 else ()           # two-plane caches: [plane][...]
+        self.k_self = [z(*pl, self.R, d.kv_heads, self.T, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
+        self.v_self = [z(*pl, self.R, d.kv_heads, self.T, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
+        self.k_cross = [z(*pl, B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
+        self.v_cross = [z(*pl, B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
+        self.kv_plane_self = self.R * d.kv_heads * self.T * HEAD_DIM if self.kv_planes > 1 else 0
+        self.kv_plane_cross = B * d.cross_query_heads * self.S * HEAD_DIM if self.kv_planes > 1 else 0
         self.text_len = torch.tensor(self.lens, dtype=torch.int32, device=dev)
         nsc = max(hb.lib().dia_attn_scratch_floats(self.R, d.kv_heads, self.T),
                   hb.lib().dia_attn_scratch_floats(B, d.cross_query_heads, self.S))
@@ -481,6 +489,7 @@ class DecodeSession:
         ed.C, ed.V, ed.B, ed.T, ed.S = self.C, self.V, self.B, self.T, self.S
         ed.kv_dtype, ed.rows_pad, ed.ld_logits = self.kv_code, self.rows_pad, self.ld_logits
         ed.v_blocked = self.v_blocked
+        ed.kv_plane_self, ed.kv_plane_cross = self.kv_plane_self, self.kv_plane_cross
         ed.eps = float(self.cfg.model.normalization_layer_epsilon)
         ed.layers = C.cast(self._layers, C.POINTER(hb.DecLayer))
         ed.w_logits, ed.kt_logits, ed.ns_logits = hb.ptr(w.logits.t), w.logits.kt, w.logits.ns
@@ -595,6 +604,7 @@ class DecodeSession:
                     g.kv_vblocked = self.v_blocked if kv is not None else 0
                     if kv is not None:
                         g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = kv
+                        g.kv_plane_stride = self.kv_plane_cross
                         g.cos_t, g.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
                     if row_map:
                         g.row_b, g.seg_off = hb.ptr(row_b), hb.ptr(seg_off)
@@ -649,7 +659,7 @@ class DecodeSession:
     def _prompt_prefill_batched(self) -> bool:
         """The batched MFMA prefill of the prompt rows needs bf16 caches with the blocked V layout and an
         uncompacted decoder; everything else replays the prompt rows through the decode step (first_step)."""
-        return (any(f > 2 for f in self.first_steps) and self.v_blocked == 1 and not self.w.compacted and not self.teacher
+        return (any(f > 2 for f in self.first_steps) and self.v_blocked == 1 and self.kv_code == hb.KV_BF16 and not self.w.compacted and not self.teacher
                 and self.prompt_prefill != "replay" and self.w.weight_planes == 1)
 
     def _prompt_prefill(self, st):
@@ -926,7 +936,7 @@ class DecodeSession:
     def step_bytes(self, n_keys: Optional[int] = None) -> int:
         """Algorithmic HBM bytes of one decode step at self-KV length `n_keys` (default: current)."""
         d = self.cfg.model.decoder
-        kvb = 4 if self.kv_code == hb.KV_F32 else 2
+        kvb = 2 if self.kv_code == hb.KV_BF16 else 4       # fp32, or two bf16 planes
         if n_keys is None:
             n_keys = int(self.cur.max().item())
         kv_self = 2 * d.n_layer * 2 * d.kv_heads * HEAD_DIM * kvb * n_keys      # both rows, K and V

@@ -28,6 +28,8 @@ extern "C" {
 
 #define DIA_KV_F32 0       /* parity mode: K/V caches in float32 */
 #define DIA_KV_BF16 1      /* perf mode (reference GPU bf16 path, state.py:142-151) */
+#define DIA_KV_BF16X2 2    /* every K / V value as hi + lo bf16 (16 significand bits) in two planes of the bf16 layouts, `kv_plane_stride`
+                            * elements apart: the bytes of the fp32 caches, the MFMA attention kernel, logits within 1e-3 of the fp32 path */
 
 /* GEMM epilogues */
 #define DIA_EPI_SCALE_STORE 0  /* out[m][n] = acc * inv_rms[m]                      (q/k/v, cross-q, logits) */
@@ -138,6 +140,7 @@ typedef struct {
    * products of a genuine fp32 checkpoint, exact like the activations' — through the generic kernel only (no split-K, no
    * persistent forms): the parity configuration for checkpoints that bf16 cannot hold, not a fast path. */
   int32_t w_planes;
+  int64_t kv_plane_stride;  /* CROSSKV with kv_dtype DIA_KV_BF16X2: elements between the hi and the lo plane of kc / vc */
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
@@ -195,6 +198,7 @@ typedef struct {
    * attention kernel; 0: V stored [key][128] -> the VALU kernel (required for fp32 caches and ENC) */
   int32_t v_blocked;
   int32_t act_f32;          /* 1: P receives fp32 activation tiles (dia_gemm_args.act_f32) instead of three planes */
+  int64_t kv_plane_stride;  /* DIA_KV_BF16X2: elements between the hi and the lo plane of kc / vc */
 } dia_attn_args;
 int dia_attn(const dia_attn_args* a, void* stream);
 int dia_attn_scratch_floats(int n_rows, int n_kv_heads, int kv_cap);
@@ -421,6 +425,7 @@ typedef struct {
    * co, wi, wo of layer l and, for l + 1 < n_layer, qkv of layer l + 1), used when 2B <= 4 */
   const void* const* seg_w;
   void* seg_ws;             /* workspace of dia_seg_mlp */
+  int64_t kv_plane_self, kv_plane_cross;   /* DIA_KV_BF16X2: plane strides (elements) of the self / cross caches */
 } dia_engine_desc;
 
 typedef struct dia_engine dia_engine;

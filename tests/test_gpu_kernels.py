@@ -293,7 +293,7 @@ def attn_ref(q, K, V):
     return p @ V
 
 
-@pytest.mark.parametrize("kvd", ["f32", "bf16"])
+@pytest.mark.parametrize("kvd", ["f32", "bf16", "bf16x2"])
 @pytest.mark.parametrize("B,cur,nz", [(1, 1, 0), (1, 37, 0), (1, 128, 0), (1, 129, 0), (2, 300, 0), (1, 1025, 0), (1, 1280, 0),
                                       (1, 1025, 1), (2, 300, 2), (1, 1280, 3), (1, 640, 2)])
 def test_attn_self(kvd, B, cur, nz, tuning):
@@ -307,18 +307,25 @@ def test_attn_self(kvd, B, cur, nz, tuning):
     nq = (QH + 2 * KVH) * 128
     qkv = torch.randn(R, nq, device=d)
     kdt = torch.float32 if kvd == "f32" else torch.bfloat16
-    kc = (torch.randn(R, KVH, T, 128, device=d)).to(kdt)
-    vc = (torch.randn(R, KVH, T, 128, device=d)).to(kdt)
-    blocked = kvd == "bf16"                       # bf16 caches: V blocked, MFMA kernel
-    if blocked:
-        vc = lay.v_to_blocked(vc)
+    two = kvd == "bf16x2"                         # every value as hi + lo bf16 in two planes (16 significand bits)
+    kf, vf = torch.randn(R, KVH, T, 128, device=d), torch.randn(R, KVH, T, 128, device=d)
+    blocked = kvd != "f32"                        # bf16 caches: V blocked, MFMA kernel
+    if two:
+        khi, vhi = kf.bfloat16(), vf.bfloat16()
+        klo, vlo = (kf - khi.float()).bfloat16(), (vf - vhi.float()).bfloat16()
+        kc = torch.stack([khi, klo]).contiguous()
+        vc = torch.stack([lay.v_to_blocked(vhi), lay.v_to_blocked(vlo)]).contiguous()
+    else:
+        kc, vc = kf.to(kdt), vf.to(kdt)
+        if blocked:
+            vc = lay.v_to_blocked(vc)
     kc0, vc0 = kc.clone(), vc.clone()
     cos, sin = [t.to(d) for t in lay.rope_tables(T + 1, 128, 1, 10000)]
     curs = torch.full((B,), cur, dtype=torch.int32, device=d)
     mt = (R + 15) // 16
     P = torch.zeros(3, mt, QH * 128 // 32, 64, 8, dtype=torch.bfloat16, device=d)
     a = hb.AttnArgs()
-    a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_SELF, (0 if kvd == "f32" else 1), KVH, 4, R, T
+    a.mode, a.kv_dtype, a.n_kv_heads, a.group, a.n_rows, a.kv_cap = hb.ATTN_SELF, {"f32": 0, "bf16": 1, "bf16x2": 2}[kvd], KVH, 4, R, T
     a.q, a.ldq, a.q_off, a.k_off, a.v_off = hb.ptr(qkv), nq, 0, QH * 128, (QH + KVH) * 128
     a.kc, a.vc, a.cur = hb.ptr(kc), hb.ptr(vc), hb.ptr(curs)
     a.cos_t, a.sin_t = hb.ptr(cos), hb.ptr(sin)
@@ -327,12 +334,17 @@ def test_attn_self(kvd, B, cur, nz, tuning):
     tk = torch.zeros(R * KVH, dtype=torch.int32, device=d)
     a.scratch, a.tickets = hb.ptr(scr), hb.ptr(tk)
     a.v_blocked = int(blocked)
+    a.kv_plane_stride = kc[0].numel() if two else 0
     for _ in range(2):                                  # second launch: tickets were re-zeroed by the kernel
         kc.copy_(kc0); vc.copy_(vc0)
         hb.check(hb.lib().dia_attn(C.byref(a), None), "dia_attn")
     torch.cuda.synchronize()
     assert (tk == 0).all()
-    if blocked:
+    if two:        # the value a two-plane cache holds is hi + lo
+        kc, kc0 = kc[0].float() + kc[1].float(), kc0[0].float() + kc0[1].float()
+        vc = lay.v_from_blocked(vc[0]).float() + lay.v_from_blocked(vc[1]).float()
+        vc0 = lay.v_from_blocked(vc0[0]).float() + lay.v_from_blocked(vc0[1]).float()
+    elif blocked:
         vc, vc0 = lay.v_from_blocked(vc), lay.v_from_blocked(vc0)
     out = lay.unpack_planes(P, R, QH * 128).double().reshape(R, QH, 128)
 
@@ -347,8 +359,9 @@ def test_attn_self(kvd, B, cur, nz, tuning):
         knew, vnew = knew.float().bfloat16().double(), vnew.float().bfloat16().double()
     slot = cur - 1
     # cache append (state.py:99-103): slot written, everything else untouched
-    assert (kc[:, :, slot].double() - knew).abs().max().item() <= (1e-6 if kvd == "f32" else 0.0) + 1e-6
-    assert (vc[:, :, slot].double() - vnew).abs().max().item() <= 1e-6
+    tol_new = 6e-5 if two else 1e-6            # hi + lo keeps 16 significand bits of values up to ~8
+    assert (kc[:, :, slot].double() - knew).abs().max().item() <= (1e-6 if kvd == "f32" else 0.0) + tol_new
+    assert (vc[:, :, slot].double() - vnew).abs().max().item() <= tol_new
     keep = torch.ones(T, dtype=torch.bool, device=d); keep[slot] = False
     assert torch.equal(kc[:, :, keep], kc0[:, :, keep]) and torch.equal(vc[:, :, keep], vc0[:, :, keep])
     worst = 0.0

@@ -676,7 +676,7 @@ def test_full_size_bf16_kv_vs_oracle(full):
     mt = steps + 1
     r, nz = oracle_run(cfg, sd, TEXTS[0], 42, mt, max_steps=steps)
     out = {}
-    for kv in ("f32", "bf16"):
+    for kv in ("f32", "bf16x2", "bf16"):
         logits, res = teacher_forced(w, cfg, [TEXTS[0]], [r.tokens], [nz[: mt - 1]], mt, kv=kv)
         worst = max(float(np.abs(logits[i][0] - r.logits[i]).max()) for i in range(len(r.logits)))
         agree = float(np.mean([np.array_equal(res[0].preds[1 + i], p) for i, p in enumerate(r.preds)]))
@@ -690,6 +690,8 @@ def test_full_size_bf16_kv_vs_oracle(full):
         print(f"Dia-1.6B {kv} K/V vs fp32 oracle: {steps} teacher-forced steps logits max-abs err {worst:.3e}, "
               f"sample agreement {agree:.3f}, free-running identical rows {prefix}/{mt}")
     assert out["f32"][0] <= LOGIT_TOL and out["f32"][1] == 1.0 and out["f32"][2] == mt
+    # two bf16 planes per K / V value (the bytes of the fp32 caches, MFMA attention): inside the north-star bound, samples identical
+    assert out["bf16x2"][0] <= LOGIT_TOL and out["bf16x2"][1] == 1.0 and out["bf16x2"][2] == mt
     assert out["bf16"][0] <= BF16_KV_LOGIT_BOUND_FULL and out["bf16"][1] >= 0.8
 
 
@@ -838,6 +840,11 @@ def test_long_horizon_1024_steps_vs_oracle():
     print(f"long horizon, fp32 K/V, batch 3 (text 0 / 300 / 1024): logits max-abs err per utterance "
           f"{[float(f'{e:.2e}') for e in errs3.max(axis=0)]}, samples identical {agree3.mean():.4f}")
     assert errs3.max() <= LOGIT_TOL and agree3.all()
+    # two-plane bf16 K/V: the MFMA attention kernel inside the parity bound over the whole horizon
+    err2, agree2 = run("bf16x2", [0, 1, 2])
+    print(f"long horizon, bf16x2 K/V, batch 3: logits max-abs err per utterance {[float(f'{e:.2e}') for e in err2.max(axis=0)]}, "
+          f"samples identical {agree2.mean():.4f}")
+    assert err2.max() <= LOGIT_TOL and agree2.all()
     # bf16 K/V (perf configuration): error growth over the same steps
     errb, agreeb = run("bf16", [2])
     q = [float(errb[a:b].max()) for a, b in ((0, 256), (256, 512), (512, 768), (768, 1024))]
