@@ -198,25 +198,21 @@ __global__ __launch_bounds__(SG_NT) void k_seg_mlp(SegK p) {
   if (w < SG_NCW) {
     // ------------------------------------------------------------------ streaming waves
     bf16x8 buf[SG_NB][SG_TILES];
-    if (p.stamps && tid == 0) p.stamps[4096 + cu * 16 + 0] = sg_clock();
     // the sync wave's first loads (16 KiB of attention output + the residual row) must be in the CU's memory queue AHEAD of
     // the weight stream — that queue is served in order, and 336 KiB of weights in front of them cost 11 us — and so must
     // the slots of the first op: a short sleep instead of a barrier (arrays kept in registers across a barrier went to scratch)
     for (int i = 0; i < (w >= SG_S_CO ? 2 * p.head_sleep : p.head_sleep); ++i) __builtin_amdgcn_s_sleep(1);
-    if (p.stamps && tid == 0) p.stamps[4096 + cu * 16 + 5] = sg_clock();
 #pragma unroll
     for (int k = 0; k < SG_NB; ++k) {
       const int s = w + SG_NCW * k;
       if (s < nslots) sg_load_slot(buf[k], p.W, cu, nslots, s, lane, p.dbg);
     }
-    if (p.stamps && tid == 0) p.stamps[4096 + cu * 16 + 6] = sg_clock();
     {   // rows >= M of every group of 4 stay zero for the whole launch
       bf16x8* planes = reinterpret_cast<bf16x8*>(smem + SG_L_PLANES);
       const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int i = tid; i < SG_TILES * 64; i += SG_NCW * 64)
         if ((i & 3) >= M) { planes[i] = z; planes[SG_TILES * 64 + i] = z; planes[2 * SG_TILES * 64 + i] = z; }
     }
-    if (p.stamps && tid == 0) p.stamps[4096 + cu * 16 + 1] = sg_clock();
     int cur = -1;                     // op whose planes are ready (its barrier B has been passed)
     auto advance_to = [&](int op) {
       while (cur < op) {
@@ -273,9 +269,6 @@ __global__ __launch_bounds__(SG_NT) void k_seg_mlp(SegK p) {
       const float4* src = reinterpret_cast<const float4*>(p.a_in + ((long)kt * 64 + row + 16 * q) * 8);
       fa[u] = src[0]; fb[u] = src[1];
     }
-    if (p.stamps && lane == 0) p.stamps[4096 + cu * 16 + 2] = sg_clock();
-    if (p.stamps && lane == 0 && fa[0].x != 12345.f) p.stamps[4096 + cu * 16 + 3] = sg_clock();
-    if (p.stamps && lane == 0 && fb[SG_MAXM * 4 - 1].x != 12345.f) p.stamps[4096 + cu * 16 + 4] = sg_clock();
 #pragma unroll
     for (int u = 0; u < SG_MAXM * 4; ++u) {
       const int f = u * 64 + lane, row = f >> 8, idx = f & 255;

@@ -19,7 +19,7 @@ x = torch.zeros(16, 2048, device=dev); x[:M] = x0
 planes_x = torch.zeros(3, 1, 64, 64, 8, dtype=torch.bfloat16, device=dev)
 ssq = torch.zeros(128, 16, device=dev); qkv = torch.zeros(16, 3072, device=dev)
 ws = torch.zeros(int(L.dia_seg_workspace_bytes()), dtype=torch.uint8, device=dev)
-stamps = torch.zeros(2 * 256, 16, dtype=torch.int64, device=dev)
+stamps = torch.zeros(256, 16, dtype=torch.int64, device=dev)
 def args(ring, st):
     s = hb.SegArgs()
     s.a_in, s.a_ktiles, s.M, s.W, s.nslots, s.has_qkv, s.D, s.F = hb.ptr(a_t), 64, M, hb.ptr(ring), 29, 1, 2048, 8192
@@ -43,8 +43,7 @@ for rep in range(3):
     ev1.record(); torch.cuda.synchronize()
     print(f"24 eager launches: {ev0.elapsed_time(ev1) / 24 * 1e3:.2f} us per launch (host-paced)")
 assert L.dia_seg_error(hb.ptr(ws), None) == 0
-st_all = stamps.cpu().numpy().astype(np.float64) / 100.0      # us
-st, ex = st_all[:256], st_all[256:]
+st = stamps.cpu().numpy().astype(np.float64) / 100.0      # us
 t0 = st[:, 0].min()
 names = ["start", "attn rows in LDS", "planes(co) ready", "co computed", "x1 published", "x1 complete (all CUs)", "x1 gathered",
          "wi computed", "h published", "h quarter complete", "wo computed", "wo partial out / reduced+x2 published", "x2 complete", "x2 gathered",
@@ -54,6 +53,3 @@ for i, nme in enumerate(names):
     v = st[:, i] - t0
     print(f"{i:2d} {nme:39s} {v.min():7.2f} {np.median(v):7.2f} {v.max():7.2f}")
 
-for i, nme in enumerate(["wave 0 start", "wave 0 first slots requested + zero fill", "sync: loads issued", "sync: first fragment arrived", "sync: last fragment arrived", "wave 0 after its head sleep", "wave 0 slots requested"]):
-    v = ex[:, i] - t0
-    print(f"x{i} {nme:39s} {v.min():7.2f} {np.median(v):7.2f} {v.max():7.2f}")
