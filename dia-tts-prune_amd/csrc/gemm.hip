@@ -772,6 +772,232 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
 
 
 // ---------------------------------------------------------------------------------------------------
+// 17..128 rows, K = 2048, dense decode shapes (qkv, o, cq, co, wi, logits at batch 9-64): TWO m-tiles per workgroup.
+// The z-form above streams every weight byte once per m-tile through L2 -> CU (eight times at 128 rows: 536 MB per wi
+// launch, the L2's practical limit: profiles/r03_pmc_zform_l2.txt) and pays the per-strip reduce / epilogue once per
+// m-tile.  Here a workgroup multiplies each strip it loads against 32 rows: its waves still split K eight ways, the hi
+// and mid planes of both m-tiles' A fragments stay in registers (128 VGPRs), the lo planes in a wave-private part of
+// LDS (2 x 8 KiB per wave), all 512 threads take one element of the two finished 16 x 16 tiles each.  gridDim.z = pairs
+// of m-tiles (the last pair may hold one).  Same arithmetic in the same order as k_gemm16: results are bit-identical.
+// fp32 activation tiles in and out; epilogues SCALE_STORE / RESID_EMIT / SWIGLU_EMIT without compaction maps.
+constexpr size_t g2t_smem() { return (size_t)2 * 8 * 8 * 64 * 16 + sizeof(f32x4) * 2 * 8 * 64 + 2 * 1024 + sizeof(float) * 32; }
+template <bool SPLITK>
+__global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
+                                               int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
+  constexpr int NW = 8, KPW = 8;
+  p.A = a_A; p.a_plane_stride = a_aps; p.W = a_W; p.KT = a_KT; p.M = a_M; p.epi = a_epi; p.nstrips = a_nstrips;
+  p.out = a_out; p.ldo = a_ldo; p.gnext = a_gnext;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16x8* alo = reinterpret_cast<bf16x8*>(smem_raw);                                           // [2 tiles][NW][KPW][64]
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw + (size_t)2 * NW * KPW * 64 * 16);             // [2 tiles][NW][64]
+  float* stgf = reinterpret_cast<float*>(smem_raw + (size_t)2 * NW * KPW * 64 * 16 + sizeof(f32x4) * 2 * NW * 64);   // [2 tiles][16][16]
+  float* inv_s = stgf + 2 * 256;                                                               // [32]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int mtiles = (p.M + 15) >> 4;
+  const int mt0 = 2 * blockIdx.z;                          // first m-tile of this workgroup
+  const int Ml = min(32, p.M - 16 * mt0);                  // rows it holds (1..32)
+  const int mt1 = min(mt0 + 1, mtiles - 1);                // second m-tile, or the first once more when there is none (never stored)
+  // SPLITK (its own instantiation: behind a run-time branch its stores and atomics made the waits of the plain form conservative,
+  // wi 35 -> 42 us at 128 rows): split-K over gridDim.y workgroups (wo: four K quarters), merged by the last arriver
+  const int SK = SPLITK ? gridDim.y : 1, ks = SPLITK ? blockIdx.y : 0;
+  const int kt0 = ks * (NW * KPW) + w * KPW;
+  const int G = gridDim.x;
+  __shared__ int sk_flag;
+  const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + (long)kt0 * 64 + lane;
+  auto load_strip = [&](bf16x8* b, int strip) {
+    const bf16x8* Wt = Wl + (long)strip * p.KT * 64;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) b[i] = (gridDim.z > 1 && ZTEMPORAL) ? *(Wt + (long)i * 64) : DIA_WLOAD(Wt + (long)i * 64);
+  };
+  bf16x8 b0[KPW], b1[KPW];
+  // A fragments of both m-tiles (fp32 tiles): hi / mid to registers, lo to this wave's own LDS region
+  bf16x8 ah[2][KPW], am[2][KPW];
+  bf16x8* my = alo + (long)w * KPW * 64 + lane;            // + tile * NW * KPW * 64 + i * 64
+  {
+    const float* Af = reinterpret_cast<const float*>(p.A);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int mt = t ? mt1 : mt0;
+      const int rows = t ? max(Ml - 16, 1) : min(Ml, 16);
+      const int alane = (lane & 48) | min(lane & 15, rows - 1);
+      const float4* src = reinterpret_cast<const float4*>(Af + (((long)mt * p.a_ktiles + kt0) * 64 + alane) * 8);
+      float4 x0[KPW], x1[KPW];
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) { x0[i] = src[(long)i * 128]; x1[i] = src[(long)i * 128 + 1]; }
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        bf16x8 lo;
+        split3x8(x0[i], x1[i], ah[t][i], am[t][i], lo);
+        my[(t * NW * KPW + i) * 64] = lo;
+      }
+    }
+  }
+  // row scales of the 32 rows: 8 threads per row sum the strip partials in the order of k_gemm16
+  const bool has_norm = p.ssq_in != nullptr;
+  {
+    const int s_row = tid >> 3, s_part = tid & 7;
+    const bool s_thread = tid < 256 && has_norm;
+    float sq[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sq[i] = 0.f;
+    if (s_thread) {
+      const float* sp = p.ssq_in + 16 * mt0 + min(s_row, Ml - 1);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sq[i] = sp[(long)min(s_part + 8 * i, p.ssq_in_n - 1) * p.ssq_ld];
+    }
+    float s0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s0 += (s_part + 8 * i < p.ssq_in_n && s_row < Ml) ? sq[i] : 0.f;
+    if (s_thread && s_row < Ml)
+      for (int idx = s_part + 128; idx < p.ssq_in_n; idx += 8) s0 += p.ssq_in[(long)idx * p.ssq_ld + 16 * mt0 + s_row];
+    s0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+    s0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));
+    s0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x141, 0xF, 0xF, true));
+    if (tid < 256 && s_part == 0) inv_s[s_row] = has_norm ? rsqrtf(s0 * p.inv_d + p.eps) : 1.0f;
+  }
+  // epilogue geometry: thread t owns element (row 16 * (t >> 8) + ((t >> 4) & 15), column t & 15) of the two finished tiles
+  const int ti = tid >> 8, r16 = (tid >> 4) & 15, c16 = tid & 15;
+  const int rl = 16 * ti + r16;                            // row inside the workgroup's 32
+  const bool live = rl < Ml;
+  const long grow = 16 * mt0 + rl;                         // row of the whole batch
+  const bool resid = p.epi == DIA_EPI_RESID_EMIT;
+  float xpre1 = 0.f, gpre1 = 1.f;
+  auto load_resid = [&](int strip) {
+    const int n = strip * 16 + c16;
+    xpre1 = p.out[(live ? grow : (long)16 * mt0) * p.ldo + n];
+    gpre1 = p.gnext[n];
+  };
+  if (resid) load_resid(blockIdx.x);
+  __builtin_amdgcn_sched_barrier(0);
+  load_strip(b0, blockIdx.x);
+  __builtin_amdgcn_sched_barrier(0);
+  float* Pf = reinterpret_cast<float*>(p.P);
+
+  auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
+    const int next = strip + G;
+    load_strip(bn, DIA_PREFETCH_CLAMP(next, p.nstrips));       // unconditional: see k_gemv_small
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        const bf16x8 lo = my[(t * NW * KPW + i) * 64];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t][i], bc[i], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t][i], bc[i], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, bc[i], acc[t], 0, 0, 0);
+      }
+    red[(0 * NW + w) * 64 + lane] = acc[0];
+    red[(1 * NW + w) * 64 + lane] = acc[1];
+    lds_barrier();
+    float v;
+    {
+      const float* rf = reinterpret_cast<const float*>(red + ti * NW * 64) + (c16 + 16 * (r16 >> 2)) * 4 + (r16 & 3);
+      v = rf[0];
+#pragma unroll
+      for (int ww = 1; ww < NW; ++ww) v += rf[ww * 256];
+    }
+    bool last = true;
+    if constexpr (SPLITK) {
+      // both partial tiles leave together: one slab publication, one ticket, one merge by the last arriver in split order
+      // (the protocol of splitk_combine: sc1 stores acknowledged before the ticket, sc1 loads after it; no fences)
+      stgf[ti * 256 + r16 * 16 + c16] = v;
+      lds_barrier();
+      const __amdgpu_buffer_rsrc_t sr = agent_rsrc(p.sk_scratch);
+      const long unit = (long)blockIdx.z * p.nstrips + strip;
+      const int tt = (tid >> 6) & 1, row = (tid & 63) >> 2, c4 = (tid & 3) * 4;
+      if (tid < 128) {
+        const float* f = &stgf[tt * 256 + row * 16 + c4];
+        st4_agent(sr, (int)(((unit * SK + ks) * 512 + tt * 256 + row * 16 + c4) * 4), f32x4{f[0], f[1], f[2], f[3]});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      lds_barrier();
+      if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(p.sk_tickets + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lst = ticket == SK - 1;
+        if (lst) __hip_atomic_store(p.sk_tickets + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        sk_flag = lst;
+      }
+      lds_barrier();
+      last = sk_flag != 0;
+      if (last) {
+        if (tid < 128) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          for (int k = 0; k < SK; ++k) {
+            const f32x4 t = ld4_agent(sr, (int)(((unit * SK + k) * 512 + tt * 256 + row * 16 + c4) * 4));
+            a[0] += t[0]; a[1] += t[1]; a[2] += t[2]; a[3] += t[3];
+          }
+          float* f = &stgf[tt * 256 + row * 16 + c4];
+          f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3];
+        }
+        lds_barrier();
+        v = stgf[ti * 256 + r16 * 16 + c16];
+      }
+      lds_barrier();                                        // stgf is staged again below; red is free
+    }
+    if (!last) {
+      if (next < p.nstrips && resid) load_resid(next);
+    } else if (p.epi == DIA_EPI_SCALE_STORE) {
+      if (live) p.out[grow * p.ldo + strip * 16 + c16] = v * inv_s[rl];
+      lds_barrier();                                        // red is rewritten by the next strip
+    } else {
+      float e = 0.f;
+      bool emit = false;
+      if (resid) {
+        const int n = strip * 16 + c16;
+        const float xv = xpre1 + v;
+        if (live) p.out[grow * p.ldo + n] = xv;
+        const float sqv = mul_rn(xv, xv);
+        float accs = sqv;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+          const float t = DIA_ROW_SHR(accs, 1);
+          if ((c16 & 7) == j) accs = add_rn(t, sqv);
+        }
+        const float h0 = DIA_ROW_SHR(accs, 8);
+        if (live && c16 == 15) p.ssq_out[(long)strip * p.ssq_ld + grow] = h0 + accs;
+        e = mul_rn(xv, gpre1);
+        emit = live;
+      } else {                                              // SWIGLU: columns 0..7 gate, 8..15 up
+        const float up_raw = DIA_ROW_SHL(v, 8);
+        const float inv = inv_s[rl];
+        const float g = v * inv, u = up_raw * inv;
+        e = (g / (1.0f + expf(-g))) * u;
+        emit = live && c16 < 8;
+      }
+      stgf[ti * 256 + r16 * 16 + c16] = e;
+      lds_barrier();                                        // (also: red is free again)
+      // the staged values leave as 16-byte stores: RESID 4 per row (64 threads per tile), SWIGLU 2 per row (32 threads per tile)
+      const int tt = tid >> 6 & 1;                          // waves 0 / 1 store tile 0 / 1
+      if (tid < 128) {
+        const int u = tid & 63;
+        const int mt = mt0 + tt;
+        float* Pt = Pf + (long)mt * p.p_ktiles * 512;
+        if (resid) {
+          const int mm = u >> 2, q = u & 3;
+          if (16 * tt + mm < Ml)
+            *reinterpret_cast<float4*>(Pt + plane_frag_off(mm, strip * 16 + (q >> 1) * 8, p.p_ktiles) + (q & 1) * 4) =
+                *reinterpret_cast<const float4*>(&stgf[tt * 256 + mm * 16 + q * 4]);
+        } else if (u < 32) {
+          const int mm = u >> 1, q = u & 1;
+          if (16 * tt + mm < Ml)
+            *reinterpret_cast<float4*>(Pt + plane_frag_off(mm, strip * 8, p.p_ktiles) + q * 4) =
+                *reinterpret_cast<const float4*>(&stgf[tt * 256 + mm * 16 + q * 4]);
+        }
+      }
+      if (next < p.nstrips && resid) load_resid(next);
+      lds_barrier();                                        // the staging area is rewritten by the next strip
+    }
+  };
+  lds_barrier();          // inv_s
+  int strip = blockIdx.x;                                   // strip pairs, then at most one more (see k_gemv_small)
+  for (; strip + G < p.nstrips; strip += 2 * G) {
+    body(b0, b1, strip);
+    body(b1, b0, strip + G);
+  }
+  if (strip < p.nstrips) body(b0, b1, strip);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Prefill GEMM (encoder layers, cross-K/V projections: M = text bytes, tens to thousands of rows).
 // Here the contraction is dense and MFMA is the roofline, not HBM: a workgroup owns a 64-row x 256-column
 // output block; its 8 waves form a 2 x 4 grid, each wave = 2 m-tiles x 4 strips of 16 columns, running the
@@ -1170,6 +1396,8 @@ extern "C" int dia_dbg_stamps(long long* host, int n) {
 
 int dia_gemm_init() {
   int rc = 0;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem()) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem()) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 4, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 4))) != hipSuccess) rc = 1;
@@ -1282,6 +1510,22 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   const int mz_max = dia_tune(DIA_TUNE_GEMM_MZ_MAX) >= 0 ? dia_tune(DIA_TUNE_GEMM_MZ_MAX) : 8;
   // (the z-form's 32-thread tail runs the shared epilogue: the cross-K/V projections of a short prompt ride it too — the generic
   // kernel they fell to spills and took 21-25 us per launch at 98 rows)
+  // dense K = 2048 decode shapes with fp32 tiles on both sides: two m-tiles per workgroup (k_gemm2t)
+  if (mtiles >= 2 && mtiles <= mz_max && a->KT == 64 * sk && fast_epi && a->epi != DIA_EPI_CROSSKV && k.a_f32 && (!emits_ || k.p_f32) &&
+      (sk == 1 || (mtiles >= 2 && a->sk_scratch_floats >= (int64_t)((mtiles + 1) / 2) * a->nstrips * sk * 512)) &&
+      !a->cmap && !a->strip_map && a->w_planes <= 1 && dia_tune(DIA_TUNE_GEMM_2T) != 0 &&
+      // measured (profiles/r03_gemm2t_ab.txt): it wins where a workgroup walks many strips — wi at every row count (35 vs 52 us at 128
+      // rows), the logits head from three m-tiles on; the 128..192-strip projections run as fast or faster in the z-form (more workgroups)
+      (a->nstrips >= 1024 || (a->nstrips >= 512 && mtiles >= 3) || sk > 1 || dia_tune(DIA_TUNE_GEMM_2T) == 2)) {
+    const int zp = (mtiles + 1) / 2;
+    int per = 256 / zp / sk;
+    per = per >= 8 ? per / 8 * 8 : (per > 0 ? per : 1);
+    int gx = (a->nstrips + ((a->nstrips + per - 1) / per) - 1) / ((a->nstrips + per - 1) / per);      // strips per workgroup = ceil(nstrips / per)
+    if (gx % 8 != 0 && (gx + 7) / 8 * 8 <= a->nstrips) gx = (gx + 7) / 8 * 8;                     // the pairs of one strip group on one XCD
+    if (sk > 1) launch_small_kernel<k_gemm2t<true>>(dim3(gx, sk, zp), dim3(512), g2t_smem(), st, k);
+    else launch_small_kernel<k_gemm2t<false>>(dim3(gx, 1, zp), dim3(512), g2t_smem(), st, k);
+    return dia_check_launch("k_gemm2t");
+  }
   const bool z_epi = fast_epi || a->epi == DIA_EPI_CROSSKV;
   if (mtiles >= 2 && mtiles <= mz_max && z_epi && nw16 && (sk == 1 || a->sk_scratch_floats >= (int64_t)mtiles * a->nstrips * sk * 256)) {
     bool handled = false;

@@ -17,6 +17,7 @@ enum dia_tune_id {
   DIA_TUNE_WO_SPW,
   DIA_TUNE_ACT_F32,            // act_f32: 0 = the decode step keeps three bf16 activation planes between its kernels; 1 / unset =
                                // fp32 activation tiles (read by the host side when it builds a session)
+  DIA_TUNE_GEMM_2T,            // gemm_2t: 0 = 17..128 rows never take the two-m-tile kernel k_gemm2t (K = 2048 dense shapes)
   DIA_TUNE_GEMM_ZR,            // gemm_zr: 0 = 17..128 rows keep the one-strip-ahead z-form of k_gemm16 instead of the ring form k_gemm16_zr
   DIA_TUNE_SEG,                // seg: 1 = batch 1-2 sessions run persistent MLP segments (dia_seg_mlp) when the model carries ring
                                // arenas (DeviceWeights(seg="on")); unset / 0 = the eight-launch layer (read by the host side)

@@ -363,7 +363,7 @@ class DecodeSession:
         ns_max = max([self.D // 16, w.logits.ns] + [DL[k].ns for DL in w.dec_layers for k in ("qkv", "o", "cq", "co", "wi", "wo")])
         n_scr = max((self.D // 16) * 4 * 512, ns_max * 2 * 512 if 16 < self.R <= 32 else 0)
         if 16 < self.R <= 128:   # 2..8 m-tiles: wo splits K four ways for every m-tile (k_gemm16 over gridDim.z)
-            n_scr = max(n_scr, -(-self.R // 16) * (self.D // 16) * 4 * 256)
+            n_scr = max(n_scr, 2 * -(-self.R // 32) * (self.D // 16) * 4 * 256)       # (whole PAIRS of m-tiles: k_gemm2t hands two tiles over together)
         if 16 < self.R <= 32:    # k_gemm_blk32: column blocks x K ranges of >= 8 k-tiles, 512 floats per strip and range
             n_scr = max([n_scr, w.logits.ns * -(-w.logits.kt // 8) * 512] +
                         [DL[k].ns * -(-DL[k].kt // 8) * 512 for DL in w.dec_layers for k in ("qkv", "o", "cq", "co", "wi", "wo")])
