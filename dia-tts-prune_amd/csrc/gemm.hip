@@ -780,11 +780,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
 // LDS (2 x 8 KiB per wave), all 512 threads take one element of the two finished 16 x 16 tiles each.  gridDim.z = pairs
 // of m-tiles (the last pair may hold one).  Same arithmetic in the same order as k_gemm16: results are bit-identical.
 // fp32 activation tiles in and out; epilogues SCALE_STORE / RESID_EMIT / SWIGLU_EMIT without compaction maps.
-constexpr size_t g2t_smem() { return (size_t)2 * 8 * 8 * 64 * 16 + sizeof(f32x4) * 2 * 8 * 64 + 2 * 1024 + sizeof(float) * 32; }
-template <bool SPLITK>
+// KPW = 8 (K = 2048 per workgroup) or 4 (K = 1024: the encoder's shapes); AF32 = fp32 activation tiles in and out with the 512-thread
+// tail (decode), else planes in and out with the 32-threads-per-tile tail through the shared epilogue (every epilogue incl. CROSSKV and
+// the compaction maps: the short-prompt prefill, 33..128 rows).
+constexpr size_t g2t_smem(int kpw) { return (size_t)2 * 8 * kpw * 64 * 16 + sizeof(f32x4) * 2 * 8 * 64 + 2 * 1024 + sizeof(float) * 32; }
+template <int KPW, bool AF32, bool SPLITK>
 __global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
                                                int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
-  constexpr int NW = 8, KPW = 8;
+  constexpr int NW = 8;
   p.A = a_A; p.a_plane_stride = a_aps; p.W = a_W; p.KT = a_KT; p.M = a_M; p.epi = a_epi; p.nstrips = a_nstrips;
   p.out = a_out; p.ldo = a_ldo; p.gnext = a_gnext;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps,
   // A fragments of both m-tiles (fp32 tiles): hi / mid to registers, lo to this wave's own LDS region
   bf16x8 ah[2][KPW], am[2][KPW];
   bf16x8* my = alo + (long)w * KPW * 64 + lane;            // + tile * NW * KPW * 64 + i * 64
-  {
+  if constexpr (AF32) {
     const float* Af = reinterpret_cast<const float*>(p.A);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -829,6 +832,20 @@ __global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps,
         bf16x8 lo;
         split3x8(x0[i], x1[i], ah[t][i], am[t][i], lo);
         my[(t * NW * KPW + i) * 64] = lo;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int mt = t ? mt1 : mt0;
+      const int rows = t ? max(Ml - 16, 1) : min(Ml, 16);
+      const int alane = (lane & 48) | min(lane & 15, rows - 1);
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        const long off = (((long)mt * p.a_ktiles + kt0 + i) * 64 + alane) * 8;
+        ah[t][i] = *reinterpret_cast<const bf16x8*>(p.A + off);
+        am[t][i] = *reinterpret_cast<const bf16x8*>(p.A + p.a_plane_stride + off);
+        my[(t * NW * KPW + i) * 64] = *reinterpret_cast<const bf16x8*>(p.A + 2 * p.a_plane_stride + off);
       }
     }
   }
@@ -867,7 +884,30 @@ __global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps,
     xpre1 = p.out[(live ? grow : (long)16 * mt0) * p.ldo + n];
     gpre1 = p.gnext[n];
   };
-  if (resid) load_resid(blockIdx.x);
+  // planes path: 32 threads per tile, 8 tile elements each, through the shared epilogue (as the z-form's tail)
+  // (tile 0: the first 32 lanes of wave 0, tile 1: of wave 1 — the tile is wave-uniform, so its shifted pointers stay scalar)
+  const int e_t = __builtin_amdgcn_readfirstlane(tid >> 6) & 1, e_r = (tid >> 1) & 15, e_half = tid & 1;
+  const bool e_thread = !AF32 && tid < 128 && (tid & 63) < 32, e_live = e_thread && 16 * e_t + e_r < Ml;
+  GemmK pe = p;                                            // this thread's m-tile: row-indexed pointers shifted (CROSSKV addresses rows globally)
+  if constexpr (!AF32) {
+    const int mt = mt0 + e_t;
+    if (pe.out) pe.out += (long)16 * mt * p.ldo;
+    if (pe.P) pe.P += (long)mt * p.p_ktiles * 512;
+    if (pe.ssq_out) pe.ssq_out += 16 * mt;
+  }
+  float xpre8[8], gpre8[8];
+  auto load_resid8 = [&](int strip) {
+    const int n0 = strip * 16 + e_half * 8;
+    const float* o = pe.out + (long)(e_live ? e_r : 0) * p.ldo + n0;
+    const float4 xa = *reinterpret_cast<const float4*>(o), xb = *reinterpret_cast<const float4*>(o + 4);
+    xpre8[0] = xa.x; xpre8[1] = xa.y; xpre8[2] = xa.z; xpre8[3] = xa.w;
+    xpre8[4] = xb.x; xpre8[5] = xb.y; xpre8[6] = xb.z; xpre8[7] = xb.w;
+    const float4 ga = *reinterpret_cast<const float4*>(p.gnext + n0), gb = *reinterpret_cast<const float4*>(p.gnext + n0 + 4);
+    gpre8[0] = ga.x; gpre8[1] = ga.y; gpre8[2] = ga.z; gpre8[3] = ga.w;
+    gpre8[4] = gb.x; gpre8[5] = gb.y; gpre8[6] = gb.z; gpre8[7] = gb.w;
+  };
+  if constexpr (AF32) { if (resid) load_resid(blockIdx.x); }
+  else { if (resid && e_thread) load_resid8(blockIdx.x); }
   __builtin_amdgcn_sched_barrier(0);
   load_strip(b0, blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
@@ -934,7 +974,18 @@ __global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps,
       }
       lds_barrier();                                        // stgf is staged again below; red is free
     }
-    if (!last) {
+    if constexpr (!AF32) {
+      // planes / every epilogue: the finished tiles in LDS rows, 32 threads per tile run the shared epilogue
+      if (last) stgf[ti * 256 + r16 * 16 + c16] = v;
+      lds_barrier();
+      if (e_thread) {
+        const int n0 = strip * 16 + e_half * 8;
+        const int mrow = (p.epi == DIA_EPI_CROSSKV ? 16 * (mt0 + e_t) : 0) + e_r;
+        if (last) run_epilogue(p.epi == DIA_EPI_CROSSKV ? p : pe, stgf + e_t * 256 + e_r * 16, inv_s[16 * e_t + e_r], mrow, n0, e_half, strip, e_live, xpre8, gpre8);
+        if (next < p.nstrips && resid) load_resid8(next);
+      }
+      lds_barrier();
+    } else if (!last) {
       if (next < p.nstrips && resid) load_resid(next);
     } else if (p.epi == DIA_EPI_SCALE_STORE) {
       if (live) p.out[grow * p.ldo + strip * 16 + c16] = v * inv_s[rl];
@@ -1396,8 +1447,11 @@ extern "C" int dia_dbg_stamps(long long* host, int n) {
 
 int dia_gemm_init() {
   int rc = 0;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem()) != hipSuccess) rc = 1;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem()) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<4, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(4)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 4, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 4))) != hipSuccess) rc = 1;
@@ -1510,21 +1564,38 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   const int mz_max = dia_tune(DIA_TUNE_GEMM_MZ_MAX) >= 0 ? dia_tune(DIA_TUNE_GEMM_MZ_MAX) : 8;
   // (the z-form's 32-thread tail runs the shared epilogue: the cross-K/V projections of a short prompt ride it too — the generic
   // kernel they fell to spills and took 21-25 us per launch at 98 rows)
-  // dense K = 2048 decode shapes with fp32 tiles on both sides: two m-tiles per workgroup (k_gemm2t)
-  if (mtiles >= 2 && mtiles <= mz_max && a->KT == 64 * sk && fast_epi && a->epi != DIA_EPI_CROSSKV && k.a_f32 && (!emits_ || k.p_f32) &&
-      (sk == 1 || (mtiles >= 2 && a->sk_scratch_floats >= (int64_t)((mtiles + 1) / 2) * a->nstrips * sk * 512)) &&
-      !a->cmap && !a->strip_map && a->w_planes <= 1 && dia_tune(DIA_TUNE_GEMM_2T) != 0 &&
-      // measured (profiles/r03_gemm2t_ab.txt): it wins where a workgroup walks many strips — wi at every row count (35 vs 52 us at 128
-      // rows), the logits head from three m-tiles on; the 128..192-strip projections run as fast or faster in the z-form (more workgroups)
-      (a->nstrips >= 1024 || (a->nstrips >= 512 && mtiles >= 3) || sk > 1 || dia_tune(DIA_TUNE_GEMM_2T) == 2)) {
-    const int zp = (mtiles + 1) / 2;
-    int per = 256 / zp / sk;
-    per = per >= 8 ? per / 8 * 8 : (per > 0 ? per : 1);
-    int gx = (a->nstrips + ((a->nstrips + per - 1) / per) - 1) / ((a->nstrips + per - 1) / per);      // strips per workgroup = ceil(nstrips / per)
-    if (gx % 8 != 0 && (gx + 7) / 8 * 8 <= a->nstrips) gx = (gx + 7) / 8 * 8;                     // the pairs of one strip group on one XCD
-    if (sk > 1) launch_small_kernel<k_gemm2t<true>>(dim3(gx, sk, zp), dim3(512), g2t_smem(), st, k);
-    else launch_small_kernel<k_gemm2t<false>>(dim3(gx, 1, zp), dim3(512), g2t_smem(), st, k);
-    return dia_check_launch("k_gemm2t");
+  // two m-tiles per workgroup (k_gemm2t).  Decode (fp32 tiles on both sides, dense K = 2048 shapes): where a workgroup walks many strips —
+  // measured (profiles/r03_gemm2t_ab.txt): wi at every row count (35 vs 52 us at 128 rows), the logits head from three m-tiles on, wo
+  // (split-K 4, both tiles handed over together: 38 vs 58 us); the 128..192-strip projections run as fast in the z-form (more workgroups).
+  // Short prompts (planes on both sides, 33..128 rows): every GEMM of the prefill incl. the cross-K/V projections.
+  {
+    const bool f32io = k.a_f32 && (!emits_ || k.p_f32);
+    const bool planes = !k.a_f32 && !k.p_f32;
+    const int ktw = a->KT / sk;                       // k-tiles per workgroup
+    const bool shape = (ktw == 64 || (planes && ktw == 32)) && a->KT % sk == 0 && a->w_planes <= 1 && mtiles >= 2 && mtiles <= mz_max &&
+                       (sk == 1 || a->sk_scratch_floats >= (int64_t)((mtiles + 1) / 2) * a->nstrips * sk * 512);
+    const bool decode_ok = f32io && fast_epi && !a->cmap && !a->strip_map &&
+                           (a->nstrips >= 1024 || (a->nstrips >= 512 && mtiles >= 3) || sk > 1 || dia_tune(DIA_TUNE_GEMM_2T) == 2);
+    const bool prefill_ok = planes && mtiles >= 3 && (fast_epi || a->epi == DIA_EPI_CROSSKV) && !(ktw == 32 && sk > 1);
+    if (shape && (decode_ok || prefill_ok) && dia_tune(DIA_TUNE_GEMM_2T) != 0) {
+      const int zp = (mtiles + 1) / 2;
+      int per = 256 / zp / sk;
+      per = per >= 8 ? per / 8 * 8 : (per > 0 ? per : 1);
+      const int spw_ = (a->nstrips + per - 1) / per;                                              // strips per workgroup
+      int gx = (a->nstrips + spw_ - 1) / spw_;
+      if (gx % 8 != 0 && (gx + 7) / 8 * 8 <= a->nstrips) gx = (gx + 7) / 8 * 8;                   // the pairs of one strip group on one XCD
+      const dim3 grid(gx, sk, zp), blk(512);
+      if (f32io) {
+        if (sk > 1) launch_small_kernel<k_gemm2t<8, true, true>>(grid, blk, g2t_smem(8), st, k);
+        else launch_small_kernel<k_gemm2t<8, true, false>>(grid, blk, g2t_smem(8), st, k);
+      } else if (ktw == 64) {
+        if (sk > 1) launch_small_kernel<k_gemm2t<8, false, true>>(grid, blk, g2t_smem(8), st, k);
+        else launch_small_kernel<k_gemm2t<8, false, false>>(grid, blk, g2t_smem(8), st, k);
+      } else {
+        launch_small_kernel<k_gemm2t<4, false, false>>(grid, blk, g2t_smem(4), st, k);
+      }
+      return dia_check_launch("k_gemm2t");
+    }
   }
   const bool z_epi = fast_epi || a->epi == DIA_EPI_CROSSKV;
   if (mtiles >= 2 && mtiles <= mz_max && z_epi && nw16 && (sk == 1 || a->sk_scratch_floats >= (int64_t)mtiles * a->nstrips * sk * 256)) {
