@@ -464,7 +464,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   };
   // (the persistent 8 x 8 form with fp32 input takes that tail as well — unless it runs the strip-pair split-K below)
   // PAIR (host-selected instantiation): split-K with exactly two strips per workgroup, gridDim.y > 1 && 2 * gridDim.x == nstrips
-  constexpr bool ZTAIL8 = MULTI && !MZ && !PAIR && KPW == 8 && AF32;
+  constexpr bool ZTAIL8 = MULTI && !MZ && !PAIR && KPW == 8 && AF32 && !ALDS;
   constexpr bool pair = PAIR;
   constexpr bool ZT = (MZ && !ALDS) || ZTAIL8;       // the 32-thread tail
   if constexpr (ZT) { if (resid && e_thread) load_resid8(blockIdx.x); }
@@ -1267,7 +1267,17 @@ int launch_g16(const GemmK& k, hipStream_t st) {
       if (mz > 1) launch_small_kernel<k_gemm16<NW, KPW, true, true, AF32, PF32>>(dim3(gx, sk, mz), dim3(NW * 64), smem, st, k);
       else if (KPW == 8 && sk > 1 && 2 * gx == k.nstrips)      // strip pairs handed over together (wo at 5..16 rows)
         launch_small_kernel<k_gemm16<NW, (KPW == 8 ? 8 : KPW), true, false, AF32, PF32, KPW == 8>>(dim3(gx, sk), dim3(NW * 64), smem, st, k);
-      else launch_small_kernel<k_gemm16<NW, KPW, true, false, AF32, PF32>>(dim3(gx, sk), dim3(NW * 64), smem, st, k);
+      else {
+        if constexpr (NW == 8 && KPW == 8 && AF32 && PF32) {
+          // 5..16 rows, persistent form with fp32 input (wi, logits at batch 3-8): with the mid / lo planes of A in LDS the registers
+          // suffice for the element-per-thread tail (the 32-thread tail was what fitted before) — knob gemm_zr=0 / 3 keeps the old form
+          if (sk == 1 && dia_tune(DIA_TUNE_GEMM_ZR) != 0 && dia_tune(DIA_TUNE_GEMM_ZR) != 3) {
+            launch_small_kernel<k_gemm16<NW, KPW, true, false, AF32, PF32, false, true>>(dim3(gx, sk), dim3(NW * 64), g16_smem(NW) + g16_alds(NW, KPW), st, k);
+            return dia_check_launch("k_gemm16");
+          }
+        }
+        launch_small_kernel<k_gemm16<NW, KPW, true, false, AF32, PF32>>(dim3(gx, sk), dim3(NW * 64), smem, st, k);
+      }
       return dia_check_launch("k_gemm16");
     }
   }
@@ -1453,6 +1463,7 @@ int dia_gemm_init() {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<4, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(4)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, false, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 4, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 4))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 4, true, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 4))) != hipSuccess) rc = 1;
