@@ -82,6 +82,13 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   };
 
   const bool seg = e->seg;            // persistent MLP segments: co, wi, wo and the next layer's qkv in one launch
+  // <= 4 rows, OPT-IN (knob wo_diag=1; measured, not adopted): wo from its diagonal layout (256 workgroups with the whole K each, no
+  // split-K hand-off: 9.4 -> 8.8 us); it leaves one sum of squares per 8-column half strip, so what consumes x after a wo (the
+  // following q/k/v projection, the logits head) adds D / 8 partials — and their 16 extra dependent loads cost more than wo gains
+  // (qkv 4.7 -> 8.7 us, logits 8.1 -> 12.8: batch 1 1 039 -> 969 frames/s, profiles/r03_wo_diag_ab.txt)
+  bool diag = (R <= 2 || (R <= 4 && d.F <= 4096)) && d.act_f32 && d.w_planes <= 1 && dia_tune(DIA_TUNE_WO_DIAG) == 1 && !seg;     // (the image of 3-4 rows x 8192 does not fit LDS)
+  for (int l = 0; l < d.n_layer && diag; ++l) diag = e->layers[l].w_wo_diag != nullptr && e->layers[l].cmap_next == nullptr;
+  const int xn_wo = diag ? d.D / 8 : d.D / 16;
   for (int l = 0; l < d.n_layer; ++l) {
     const dia_dec_layer& L = e->layers[l];
     dia_gemm_args g = {};
@@ -89,7 +96,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     // q/k/v projection of the pre-SA-normed row (layers.py:541, 273-275)
     g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
     g.W = L.w_qkv; g.KT = L.kt_qkv; g.nstrips = L.ns_qkv; g.epi = DIA_EPI_SCALE_STORE;
-    g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
+    g.ssq_in = d.ssq; g.ssq_in_n = l > 0 ? xn_wo : d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
     g.out = d.qkv; g.ldo = nqkv; g.strip_map = L.smap_qkv;
     lend_scratch(g);
   g.act_f32 = F;            // reads x as fp32 tiles
@@ -213,6 +220,9 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
     lend_scratch(gi);
     gi.act_f32 = 3 * F; g.act_f32 = 3 * F; gi.w_planes = d.w_planes; g.w_planes = d.w_planes;
     if ((rc = dia_gemm(&gi, st))) return rc; mark(e, n++);
+    if (diag) {
+      g.W = L.w_wo_diag; g.w_layout = 1; g.nstrips = d.D / 8; g.sk = 1; g.sk_scratch = nullptr; g.sk_tickets = nullptr; g.nw = 0; g.spw = 0;
+    }
     rc = dia_gemm(&g, st);
     if (rc == DIA_E_ARG && g.sk > 1) {
       g.sk = 1;
@@ -226,7 +236,7 @@ static int enqueue_step(dia_engine* e, bool with_sampler) {
   dia_gemm_args g = {};
   g.A = d.planes_x; g.a_plane_stride = xs; g.a_ktiles = xkt; g.M = R;
   g.W = d.w_logits; g.KT = d.kt_logits; g.nstrips = d.ns_logits; g.epi = DIA_EPI_SCALE_STORE;
-  g.ssq_in = d.ssq; g.ssq_in_n = d.D / 16; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
+  g.ssq_in = d.ssq; g.ssq_in_n = xn_wo; g.ssq_ld = d.rows_pad; g.inv_d = 1.0f / d.D; g.eps = d.eps;
   g.out = d.logits; g.ldo = d.ld_logits;
   lend_scratch(g);
   g.act_f32 = F;

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
       } else {
         float e = 0.f;                              // the value whose planes are emitted
         int ecol = c16;                             // its column inside the emitted row segment
-        bool emit = false;
+        [[maybe_unused]] bool emit = false;
         if (resid) {
           if (r_thread) {
             const int n = strip * 16 + c16;
@@ -772,6 +772,92 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
 
 
 // ---------------------------------------------------------------------------------------------------
+// M <= 4 rows, long K over few strips (wo: K = 8192, N = 2048): the DIAGONAL weight layout (layout.diag_tile_weight).
+// With 16-column strips only 128 workgroups exist, so wo splits K over two workgroups per strip and pays the slab hand-off
+// (1.75 us of a 9.5 us launch).  Here a tile carries FOUR k-tiles of FOUR columns — lane l, element j =
+// W[128 t + 32 ((l & 15) >> 2) + 8 (l >> 4) + j][4 group + (l & 3)] — and the A operand carries the <= 4 rows of the matching
+// k-tile in each group of four rows, so the 16 x 16 product is block diagonal (the blocks D[4g + r][4g + c] summed over g give
+// row r, column c; the rest is ignored).  Column granularity 4: a workgroup owns 8 columns = two groups x K / 128 tiles,
+// 256 workgroups share N = 2048 with the WHOLE K each — no cross-workgroup reduction.  16 waves: waves 0..7 the first group,
+// 8..15 the second, K split eight ways inside a group.  Epilogue RESID_EMIT (x += acc; fp32 tile of x * g_next; one sum of
+// squares per 8-column half strip: the consumers add twice as many partials).  fp32 activation tiles in and out.
+template <int RS>
+__global__ __launch_bounds__(1024) void k_gemv_diag(GemmK p) {
+  constexpr int NW = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                                   // [NW][16]: lane 20g + c -> entry 4g + c
+  bf16x8* As = reinterpret_cast<bf16x8*>(smem_raw + sizeof(f32x4) * NW * 16);         // [3 planes][KT][4 kq][RS]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int KT = p.KT;                       // k-tiles of 32 (K / 32); tiles of the diagonal layout: KT / 4 per column group
+  const int TPG = KT >> 2;                   // tiles per column group
+  const int TPW = TPG >> 3;                  // tiles per wave (8 waves per group)
+  const int hs = blockIdx.x;                 // half strip: columns [8 hs, 8 hs + 8)
+  const int cg = w >> 3, wk = w & 7;
+  // ---- small operands first (vmcnt retires in order): the fp32 image of the <= RS rows, residual + norm weight
+  const int nentries = KT * 4 * RS;          // 32-byte entries (k-tile, quarter, row)
+  const float* Af = reinterpret_cast<const float*>(p.A);
+  float4 ex[RS], ey[RS];                     // (K = 8192: 1024 entries per row)
+#pragma unroll
+  for (int u = 0; u < RS; ++u) {
+    const int c = min(tid + u * 1024, nentries - 1);
+    const int row = c % RS, kq = (c / RS) & 3, kt = c / (4 * RS);
+    const float4* src = reinterpret_cast<const float4*>(Af + ((long)kt * 64 + row + 16 * kq) * 8);
+    ex[u] = src[0]; ey[u] = src[1];
+  }
+  const int er = tid >> 3, ec = tid & 7;     // epilogue thread (row, column of the 8)
+  const bool e_thread = tid < 8 * RS, e_live = e_thread && er < p.M;
+  const int n = 8 * hs + ec;
+  float xpre = 0.f, gpre = 1.f;
+  if (e_thread) { xpre = p.out[(long)(e_live ? er : 0) * p.ldo + n]; gpre = p.gnext[n]; }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- this wave's tiles (TPW <= 8 of 1 KiB): the HBM stream
+  const bf16x8* Wl = reinterpret_cast<const bf16x8*>(p.W) + ((long)(2 * hs + cg) * TPG + wk * TPW) * 64 + lane;
+  bf16x8 b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) b[i] = DIA_WLOAD(Wl + (long)min(i, TPW - 1) * 64);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < RS; ++u)
+    if (tid + u * 1024 < nentries) {
+      const int c = tid + u * 1024;
+      bf16x8 h, mi, lo;
+      split3x8(ex[u], ey[u], h, mi, lo);
+      As[c] = h; As[nentries + c] = mi; As[2 * nentries + c] = lo;
+    }
+  lds_barrier();
+  const int g = (lane & 15) >> 2, r = min(lane & 3, RS - 1), kq = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < TPW) {
+      const int kt = 4 * (wk * TPW + i) + g;
+#pragma unroll
+      for (int pl = 0; pl < DIA_NPLANES; ++pl) {
+        const bf16x8 a = As[((pl * KT + kt) * 4 + kq) * RS + r];
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i], acc, 0, 0, 0);
+      }
+    }
+  }
+  if (((lane & 15) >> 2) == (lane >> 4)) red[w * 16 + 4 * (lane >> 4) + (lane & 3)] = acc;       // diagonal block g, column c: rows in the registers
+  lds_barrier();
+  if (e_thread) {
+    // column ec of group ec >> 2: waves 8 (ec >> 2) .. +7, blocks g = 0..3, in fixed order
+    const float* rf = reinterpret_cast<const float*>(red) + ((ec >> 2) * 8 * 16 + (ec & 3)) * 4 + er;
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww)
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) v += rf[(ww * 16 + 4 * gg) * 4];
+    const float xv = xpre + v;
+    if (e_live) p.out[(long)er * p.ldo + n] = xv;
+    float sq = mul_rn(xv, xv);
+    sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+    if (e_live && ec == 0) p.ssq_out[(long)hs * p.ssq_ld + er] = sq;
+    if (e_live) reinterpret_cast<float*>(p.P)[plane_frag_off(er, n & ~7, p.p_ktiles) + (n & 7)] = mul_rn(xv, gpre);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 17..128 rows, K = 2048, dense decode shapes (qkv, o, cq, co, wi, logits at batch 9-64): TWO m-tiles per workgroup.
 // The z-form above streams every weight byte once per m-tile through L2 -> CU (eight times at 128 rows: 536 MB per wi
 // launch, the L2's practical limit: profiles/r03_pmc_zform_l2.txt) and pays the per-strip reduce / epilogue once per
@@ -992,7 +1078,7 @@ __global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps,
       lds_barrier();                                        // red is rewritten by the next strip
     } else {
       float e = 0.f;
-      bool emit = false;
+      [[maybe_unused]] bool emit = false;
       if (resid) {
         const int n = strip * 16 + c16;
         const float xv = xpre1 + v;
@@ -1457,6 +1543,8 @@ extern "C" int dia_dbg_stamps(long long* host, int n) {
 
 int dia_gemm_init() {
   int rc = 0;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_diag<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_diag<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
@@ -1495,6 +1583,21 @@ extern "C" int dia_has_experiments(void) {
 extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
   if (!a || !a->A || (!a->W && !a->sp_blocks)) return dia_fail(DIA_E_ARG, "dia_gemm: null argument");
   if (a->M <= 0 || a->KT <= 0 || a->nstrips <= 0) return dia_fail(DIA_E_ARG, "dia_gemm: empty problem");
+  if (a->w_layout == 1) {     // diagonal 4-column tiles (layout.diag_tile_weight): M <= 4, RESID_EMIT, fp32 tiles in and out
+    const int groups = a->nstrips;               // here: 8-column half strips
+    if (!a->out || !a->P || !a->ssq_out || a->ssq_ld < a->M || a->a_ktiles < a->KT) return dia_fail(DIA_E_ARG, "dia_gemm: diagonal layout: missing buffer");
+    GemmK k;
+    fill_gemmk(a, k);
+    if (a->M > 4 || a->epi != DIA_EPI_RESID_EMIT || !a->gnext || a->cmap || (a->act_f32 & 3) != 3 || a->w_planes > 1 || a->sk > 1 ||
+        a->KT % 32 != 0 || a->KT / 32 > 8 || a->p_ktiles * 32 < groups * 8 || a->ldo < groups * 8)
+      return dia_fail(DIA_E_ARG, "dia_gemm: the diagonal weight layout serves M <= 4, RESID_EMIT, fp32 tiles, K a multiple of 1024 up to 8192");
+    const int rs = a->M <= 2 ? 2 : 4;
+    const size_t smem = sizeof(f32x4) * 16 * 16 + (size_t)3 * a->KT * 4 * rs * 16;
+    if (smem > 152 * 1024) return dia_fail(DIA_E_ARG, "dia_gemm: diagonal layout: the activation image of these rows does not fit LDS (3-4 rows: K <= 4096)");
+    if (rs == 2) launch_kernel<k_gemv_diag<2>>(dim3(groups), dim3(1024), smem, (hipStream_t)stream, k);
+    else launch_kernel<k_gemv_diag<4>>(dim3(groups), dim3(1024), smem, (hipStream_t)stream, k);
+    return dia_check_launch("k_gemv_diag");
+  }
   if (a->KT > a->a_ktiles) return dia_fail(DIA_E_ARG, "dia_gemm: weight K exceeds the plane layout's K");
   if (a->a_plane_stride % 8 != 0 || a->p_plane_stride % 8 != 0) return dia_fail(DIA_E_ARG, "dia_gemm: plane stride must be a multiple of 8");
   if ((a->epi == DIA_EPI_SCALE_STORE || a->epi == DIA_EPI_RESID_EMIT) && (!a->out || (!a->strip_map && a->ldo < a->nstrips * 16) || a->ldo % 4 != 0))

@@ -17,6 +17,8 @@ enum dia_tune_id {
   DIA_TUNE_WO_SPW,
   DIA_TUNE_ACT_F32,            // act_f32: 0 = the decode step keeps three bf16 activation planes between its kernels; 1 / unset =
                                // fp32 activation tiles (read by the host side when it builds a session)
+  DIA_TUNE_WO_DIAG,            // wo_diag: 1 = <= 2 rows run wo from the diagonal layout (k_gemv_diag; experiment, measured slower end to end) — read by
+                               // the engine and by DeviceWeights, which builds the second copy of wo only then
   DIA_TUNE_GEMM_2T,            // gemm_2t: 0 = 17..128 rows never take the two-m-tile kernel k_gemm2t (K = 2048 dense shapes)
   DIA_TUNE_GEMM_ZR,            // gemm_zr: 0 = 17..128 rows keep the one-strip-ahead z-form of k_gemm16 instead of the ring form k_gemm16_zr
   DIA_TUNE_SEG,                // seg: 1 = batch 1-2 sessions run persistent MLP segments (dia_seg_mlp) when the model carries ring

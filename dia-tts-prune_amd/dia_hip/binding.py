@@ -46,6 +46,7 @@ class GemmArgs(C.Structure):
         ("row_b", C.c_void_p), ("seg_off", C.c_void_p), ("sk_scratch_floats", C.c_int64),
         ("sp_blocks", C.c_void_p), ("sp_toff", C.c_void_p),
         ("act_f32", C.c_int32), ("w_planes", C.c_int32), ("kv_plane_stride", C.c_int64),
+        ("w_layout", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 
@@ -112,7 +113,7 @@ class SampleArgs(C.Structure):
 class DecLayer(C.Structure):
     _fields_ = [
         ("w_qkv", C.c_void_p), ("w_o", C.c_void_p), ("w_cq", C.c_void_p), ("w_co", C.c_void_p),
-        ("w_wi", C.c_void_p), ("w_wo", C.c_void_p),
+        ("w_wi", C.c_void_p), ("w_wo", C.c_void_p), ("w_wo_diag", C.c_void_p),
         ("g_sa", C.c_void_p), ("g_ca", C.c_void_p), ("g_mlp", C.c_void_p),
         ("k_self", C.c_void_p), ("v_self", C.c_void_p), ("k_cross", C.c_void_p), ("v_cross", C.c_void_p),
         ("kt_qkv", C.c_int32), ("ns_qkv", C.c_int32), ("kt_o", C.c_int32), ("ns_o", C.c_int32),

@@ -183,6 +183,11 @@ class DeviceWeights:
                          hmap_self=i32(cpt.head_map(P.live_q_heads)), hmap_cross=i32(cpt.head_map(P.live_c_heads)))
             L.update(qkv=tile(qkv), o=tile(o), cq=tile(cq), co=tile(co), ckv=tile(ckv),
                      wi=tile(lay.interleave_gate_up(wi3)), wo=tile(wo))
+            # experiment (knob wo_diag=1): wo once more in the diagonal layout (4-column groups: 256 workgroups with the whole K each)
+            L["wo_diag"] = None
+            if (hb.get_tuning("wo_diag") == 1 and P is None and weight_planes == 1 and device.type == "cuda" and wo.shape[0] % 1024 == 0
+                    and wo.shape[0] <= 8192 and wo.shape[1] % 8 == 0 and nk is None):
+                L["wo_diag"] = lay.diag_tile_weight(wo)
             self.dec_layers.append(L)
         self.cmap_first = i32(cpt._cmap(plans[0].keep_qkv)) if plans[0] is not None else None
         self.seg_layers: List[torch.Tensor] = []
@@ -218,8 +223,8 @@ class DeviceWeights:
         out += [self.enc_norm, self.dec_emb]
         for L in self.dec_layers:
             out += [L["g_sa"], L["g_ca"], L["g_mlp"]] + [L[k].t for k in ("qkv", "o", "cq", "co", "ckv", "wi", "wo")]
-            out += [L[k] for k in ("cmap_ca", "cmap_mlp", "cmap_next", "smap_qkv", "smap_cq", "smap_ckv", "hmap_self", "hmap_cross")
-                    if L[k] is not None]
+            out += [L[k] for k in ("cmap_ca", "cmap_mlp", "cmap_next", "smap_qkv", "smap_cq", "smap_ckv", "hmap_self", "hmap_cross", "wo_diag")
+                    if L.get(k) is not None]
         out += [self.dec_norm, self.logits.t, self.cos_t, self.sin_t]
         out += [t for t in (self.cmap_first, self.enc_cmap_first) if t is not None]
         out += self.seg_layers
@@ -341,7 +346,7 @@ class DecodeSession:
         self.planes_x = z(3, mt, self.xkt, 64, 8, dt=torch.bfloat16)
         self.planes_a = z(3, mt, self.akt, 64, 8, dt=torch.bfloat16)
         self.planes_h = z(3, mt, self.hkt, 64, 8, dt=torch.bfloat16)
-        self.ssq = z(self.D // 16, self.rows_pad)
+        self.ssq = z(self.D // 8, self.rows_pad)          # strip sums of squares: D / 16 per row, D / 8 behind the diagonal-layout wo
         self.nqkv = (d.gqa_query_heads + 2 * d.kv_heads) * HEAD_DIM
         self.qkv = z(self.rows_pad, self.nqkv)
         self.qc = z(self.rows_pad, d.cross_query_heads * HEAD_DIM)
@@ -483,6 +488,7 @@ class DecodeSession:
             dl.k_cross, dl.v_cross = hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i])
             for f in ("cmap_ca", "cmap_mlp", "cmap_next", "smap_qkv", "smap_cq", "hmap_self", "hmap_cross"):
                 setattr(dl, f, hb.ptr(L[f]))
+            dl.w_wo_diag = hb.ptr(L.get("wo_diag"))
         ed = hb.EngineDesc()
         ed.n_layer, ed.D, ed.F = n, self.D, self.F
         ed.q_heads, ed.kv_heads, ed.cq_heads = d.gqa_query_heads, d.kv_heads, d.cross_query_heads

@@ -252,3 +252,20 @@ def seg_ring(co: torch.Tensor, wi_gate: torch.Tensor, wi_up: torch.Tensor, wo: t
             raise ValueError("seg_ring: q/k/v projection must be [2048, 3072]")
         parts.append(_seg_slots(qkv_next).reshape(SEG_CUS, 3, 16, 64, 8))
     return torch.cat(parts, dim=1).contiguous()
+
+
+def diag_tile_weight(w2d: torch.Tensor) -> torch.Tensor:
+    """[K, N] float (K % 128 == 0, N % 4 == 0) -> bf16 [N/4, K/128, 64, 8]: the diagonal layout of dia_gemm_args.w_layout = 1 (k_gemv_diag).
+    Tile t of column group g, lane l, element j = W[128 t + 32 ((l & 15) >> 2) + 8 (l >> 4) + j][4 g + (l & 3)]: four k-tiles of the group's
+    four columns side by side in the B operand of v_mfma_f32_16x16x32_bf16 (as the slots of seg_ring, for any K)."""
+    K, N = w2d.shape
+    if K % 128 or N % 4:
+        raise ValueError("diag_tile_weight: K must be a multiple of 128 and N of 4")
+    lane = torch.arange(64, device=w2d.device)
+    t = torch.arange(K // 128, device=w2d.device)
+    j = torch.arange(8, device=w2d.device)
+    k = (128 * t[:, None, None] + (32 * ((lane & 15) >> 2) + 8 * (lane >> 4))[None, :, None] + j[None, None, :])      # [K/128, 64, 8]
+    c = (lane & 3)[None, :, None].expand(K // 128, 64, 8)
+    g = w2d.reshape(K, N // 4, 4)
+    out = g[k[None], torch.arange(N // 4, device=w2d.device)[:, None, None, None], c[None]]
+    return out.to(torch.bfloat16).contiguous()

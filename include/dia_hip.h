@@ -141,6 +141,10 @@ typedef struct {
    * persistent forms): the parity configuration for checkpoints that bf16 cannot hold, not a fast path. */
   int32_t w_planes;
   int64_t kv_plane_stride;  /* CROSSKV with kv_dtype DIA_KV_BF16X2: elements between the hi and the lo plane of kc / vc */
+  int32_t w_layout;         /* 0: 16-column strips (above); 1: diagonal tiles of 4-column groups (dia_hip/layout.py diag_tile_weight): W = bf16
+                             * [N/4][K/128][64][8], `nstrips` = N/8 (8-column half strips, one workgroup each, the whole K, no split-K);
+                             * M <= 4, DIA_EPI_RESID_EMIT, fp32 tiles in and out; ssq_out receives N/8 partials per row */
+  int32_t _pad2;
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
@@ -370,6 +374,7 @@ int dia_seg_error(const void* ws, void* stream);
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
   const void *w_qkv, *w_o, *w_cq, *w_co, *w_wi, *w_wo;   /* weight tiles */
+  const void* w_wo_diag;                                 /* NULL, or wo once more in the diagonal layout (dia_gemm_args.w_layout = 1): used at <= 4 rows */
   const float *g_sa, *g_ca, *g_mlp;                      /* RMSNorm weights [D] */
   void *k_self, *v_self;                                 /* [R][kv_heads][T][128] */
   void *k_cross, *v_cross;                               /* [B][cq_heads][S][128] */

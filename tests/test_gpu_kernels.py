@@ -1095,3 +1095,43 @@ def test_gemm_fp32_weights_as_three_planes(M, K, N, epi):
     torch.cuda.synchronize()
     err1 = (get() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
     assert err1 > 20 * err, (err, err1)
+
+
+@pytest.mark.parametrize("M,K,D", [(2, 8192, 2048), (4, 4096, 2048), (1, 8192, 2048), (2, 2048, 2048), (3, 4096, 512)])
+def test_gemm_diagonal_layout_resid(M, K, D):
+    """wo at <= 4 rows from the diagonal weight layout (dia_gemm_args.w_layout = 1: 4-column groups, 256 workgroups with the
+    whole K, no split-K): x += a . W, fp32 tile of x * g_next, one sum of squares per 8-column half strip — against float64."""
+    d = dev()
+    torch.manual_seed(K + D + M)
+    a = torch.randn(M, K, device=d)
+    W = bf16r(torch.randn(K, D, device=d) * 0.03)
+    x0 = torch.randn(M, D, device=d)
+    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+    Wd = lay.diag_tile_weight(W)
+    assert tuple(Wd.shape) == (D // 4, K // 128, 64, 8)
+    A = lay.pack_f32_tiles(a, ktiles=K // 32, mtiles=1)
+    x = torch.zeros(16, D, device=d); x[:M] = x0
+    P = torch.zeros(3, 1, D // 32, 64, 8, dtype=torch.bfloat16, device=d)          # fp32 tiles live in the planes buffer
+    ssq = torch.full((D // 8, 16), float("nan"), device=d)
+    g = hb.GemmArgs()
+    g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel() * 2, K // 32, M
+    g.W, g.KT, g.nstrips, g.epi = hb.ptr(Wd), K // 32, D // 8, hb.EPI_RESID_EMIT
+    g.ssq_ld, g.out, g.ldo, g.gnext = 16, hb.ptr(x), D, hb.ptr(gn)
+    g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), D // 32, hb.ptr(ssq)
+    g.act_f32, g.w_layout = 3, 1
+    outs = []
+    for _ in range(2):
+        x[:M] = x0
+        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm(diag)")
+        torch.cuda.synchronize()
+        outs.append(x[:M].clone())
+    assert torch.equal(outs[0], outs[1])
+    ref = x0.double() + a.double() @ W.double()
+    assert (outs[0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    xt = P.view(torch.uint8).view(-1)[: (D // 32) * 64 * 8 * 4].view(torch.float32).reshape(1, D // 32, 64, 8)
+    assert torch.equal(lay.unpack_f32_tiles(xt, M, D), outs[0] * gn)
+    want = (outs[0].double() ** 2).reshape(M, D // 8, 8).sum(-1).T
+    assert (ssq[:, :M].double() - want).abs().max().item() <= 1e-5 * want.max().item()
+    # what it is not built for is refused
+    g.epi = hb.EPI_SCALE_STORE
+    assert hb.lib().dia_gemm(C.byref(g), None) == -1
