@@ -662,38 +662,68 @@ struct EncAttnK {
 };
 
 __global__ __launch_bounds__(256) void k_enc_kv_planes(EncAttnK p) {
-  // grid (heads, rows/32): one 32-row key block of one head
+  // grid (heads, rows/32): one 32-row key block of one head.  One pass: every load of the thread is requested up front (the first form
+  // walked 24 loop rounds of dependent 4-byte loads and 2-byte stores: 11.7 us per launch at any size), stores are 16 bytes per plane
   const int h = blockIdx.x, blk = blockIdx.y, tid = threadIdx.x;
   const long plane = (long)p.heads * p.rows * HD;
   bf16_raw* kp = p.kp + ((long)h * p.rows + blk * 32) * HD;
   bf16_raw* vp = p.vp + ((long)h * (p.rows >> 5) + blk) * HD * 32;
-  for (int t = tid; t < 32 * 64; t += 256) {              // K: RoPE pairs (d, d+64)
-    const int r = t >> 6, d = t & 63, m = blk * 32 + r;
-    const int b = p.row_b[m];
-    float k1 = 0.f, k2 = 0.f;
-    if (b >= 0) {
-      const int pos = m - p.seg_off[b];
-      const float* kr = p.qkv + (long)m * p.ldq + p.k_off + h * HD;
-      const float x1 = kr[d], x2 = kr[d + 64];
-      const float c = p.cos_t[(long)pos * 64 + d], s = p.sin_t[(long)pos * 64 + d];
-      k1 = x1 * c - x2 * s; k2 = x1 * s + x2 * c;
-    }
-    __bf16 a, bb, c3;
-    split3(k1, a, bb, c3);
-    kp[(long)r * HD + d] = *reinterpret_cast<bf16_raw*>(&a); kp[plane + (long)r * HD + d] = *reinterpret_cast<bf16_raw*>(&bb);
-    kp[2 * plane + (long)r * HD + d] = *reinterpret_cast<bf16_raw*>(&c3);
-    split3(k2, a, bb, c3);
-    kp[(long)r * HD + d + 64] = *reinterpret_cast<bf16_raw*>(&a); kp[plane + (long)r * HD + d + 64] = *reinterpret_cast<bf16_raw*>(&bb);
-    kp[2 * plane + (long)r * HD + d + 64] = *reinterpret_cast<bf16_raw*>(&c3);
+  // K: thread (row r, dims d0..d0+7 and their RoPE partners d0+64..): rows of padding (row_b < 0) are still rows of the qkv buffer
+  const int r = tid >> 3, d0 = (tid & 7) * 8, m = blk * 32 + r;
+  const float* kr = p.qkv + (long)m * p.ldq + p.k_off + h * HD + d0;
+  const float4 xa0 = *reinterpret_cast<const float4*>(kr), xa1 = *reinterpret_cast<const float4*>(kr + 4);
+  const float4 xb0 = *reinterpret_cast<const float4*>(kr + 64), xb1 = *reinterpret_cast<const float4*>(kr + 68);
+  // V: two items per thread, item (dim d, keys r0..r0+7) -> one 16-byte store per plane at [d][r0]
+  float vv[2][8];
+  int4 vb[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int it = tid + 256 * j, d = it >> 2, r0 = (it & 3) * 8;
+    const float* vr = p.qkv + (long)(blk * 32 + r0) * p.ldq + p.v_off + h * HD + d;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vv[j][e] = vr[(long)e * p.ldq];
+    vb[j][0] = *reinterpret_cast<const int4*>(p.row_b + blk * 32 + r0);
+    vb[j][1] = *reinterpret_cast<const int4*>(p.row_b + blk * 32 + r0 + 4);
   }
-  for (int t = tid; t < 32 * HD; t += 256) {              // V: [dim][key] inside the block
-    const int r = t & 31, d = t >> 5, m = blk * 32 + r;
-    const int b = p.row_b[m];
-    const float v = b >= 0 ? p.qkv[(long)m * p.ldq + p.v_off + h * HD + d] : 0.f;
-    __bf16 a, bb, c3;
-    split3(v, a, bb, c3);
-    vp[d * 32 + r] = *reinterpret_cast<bf16_raw*>(&a); vp[plane + d * 32 + r] = *reinterpret_cast<bf16_raw*>(&bb);
-    vp[2 * plane + d * 32 + r] = *reinterpret_cast<bf16_raw*>(&c3);
+  const int b = p.row_b[m];
+  const int pos = b >= 0 ? m - p.seg_off[b] : 0;
+  const float* ct = p.cos_t + (long)pos * 64 + d0;
+  const float* st = p.sin_t + (long)pos * 64 + d0;
+  const float4 c0 = *reinterpret_cast<const float4*>(ct), c1 = *reinterpret_cast<const float4*>(ct + 4);
+  const float4 s0 = *reinterpret_cast<const float4*>(st), s1 = *reinterpret_cast<const float4*>(st + 4);
+  {
+    const float x1[8] = {xa0.x, xa0.y, xa0.z, xa0.w, xa1.x, xa1.y, xa1.z, xa1.w};
+    const float x2[8] = {xb0.x, xb0.y, xb0.z, xb0.w, xb1.x, xb1.y, xb1.z, xb1.w};
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    bf16x8 k1[3], k2[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a1 = b >= 0 ? x1[e] * c[e] - x2[e] * s[e] : 0.f;
+      const float a2 = b >= 0 ? x1[e] * s[e] + x2[e] * c[e] : 0.f;
+      __bf16 u0, u1, u2;
+      split3(a1, u0, u1, u2); k1[0][e] = u0; k1[1][e] = u1; k1[2][e] = u2;
+      split3(a2, u0, u1, u2); k2[0][e] = u0; k2[1][e] = u1; k2[2][e] = u2;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      *reinterpret_cast<bf16x8*>(kp + pl * plane + (long)r * HD + d0) = k1[pl];
+      *reinterpret_cast<bf16x8*>(kp + pl * plane + (long)r * HD + d0 + 64) = k2[pl];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int it = tid + 256 * j, d = it >> 2, r0 = (it & 3) * 8;
+    const int rb[8] = {vb[j][0].x, vb[j][0].y, vb[j][0].z, vb[j][0].w, vb[j][1].x, vb[j][1].y, vb[j][1].z, vb[j][1].w};
+    bf16x8 v3[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      __bf16 u0, u1, u2;
+      split3(rb[e] >= 0 ? vv[j][e] : 0.f, u0, u1, u2);
+      v3[0][e] = u0; v3[1][e] = u1; v3[2][e] = u2;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(vp + pl * plane + d * 32 + r0) = v3[pl];
   }
 }
 
@@ -967,6 +997,10 @@ extern "C" int dia_enc_attn(const dia_enc_attn_args* a, void* stream) {
     return dia_fail(DIA_E_ARG, "dia_enc_attn: null argument");
   if (a->heads <= 0 || a->rows <= 0 || a->rows % 32 != 0) return dia_fail(DIA_E_ARG, "dia_enc_attn: rows must be a positive multiple of 32");
   if (a->p_plane_stride % 8 != 0 || (a->heads * 128 + 31) / 32 > a->p_ktiles) return dia_fail(DIA_E_ARG, "dia_enc_attn: output planes too narrow");
+  // k_enc_kv_planes reads q/k/v rows as float4, row_b as int4 and stores 16-byte plane chunks
+  if (a->ldq % 4 != 0 || a->k_off % 4 != 0 || a->v_off % 4 != 0 || ((uintptr_t)a->qkv & 15) || ((uintptr_t)a->row_b & 15) || ((uintptr_t)a->kp & 15) ||
+      ((uintptr_t)a->vp & 15) || ((uintptr_t)a->cos_t & 15) || ((uintptr_t)a->sin_t & 15))
+    return dia_fail(DIA_E_ARG, "dia_enc_attn: qkv / row_b / kp / vp / RoPE tables must be 16-byte aligned, ldq and the k / v offsets multiples of 4");
   EncAttnK k;
   k.qkv = a->qkv; k.ldq = a->ldq; k.q_off = a->q_off; k.k_off = a->k_off; k.v_off = a->v_off; k.heads = a->heads; k.rows = a->rows;
   k.row_b = a->row_b; k.seg_off = a->seg_off; k.seg_len = a->seg_len; k.cos_t = a->cos_t; k.sin_t = a->sin_t;

@@ -399,6 +399,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   // A fragments (rows >= M alias the last valid row: no extra L2 traffic, results never stored)
   const int alane = (lane & 48) | min(lane & 15, p.M - 1);
   bf16x8 a[KPW][DIA_NPLANES];
+  constexpr bool ALDS_LATE = ALDS && !MZ;      // see below
   if constexpr (AF32) {     // fp32 tiles (compile-time: a second operand path behind a branch would end the basic block in which
     // all loads of the wave are issued).  32 bytes per fragment; the raw values land in the registers of planes 0 and 1 of their
     // own fragment and are split in place — no second register set beside the 12 * KPW VGPRs of `a`
@@ -408,9 +409,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
       a[i][0] = __builtin_bit_cast(bf16x8, Af[(long)i * 128]);
       a[i][1] = __builtin_bit_cast(bf16x8, Af[(long)i * 128 + 1]);
     }
+    if constexpr (!ALDS_LATE) {
 #pragma unroll
-    for (int i = 0; i < KPW; ++i)
-      split3x8(__builtin_bit_cast(float4, a[i][0]), __builtin_bit_cast(float4, a[i][1]), a[i][0], a[i][1], a[i][2]);
+      for (int i = 0; i < KPW; ++i)
+        split3x8(__builtin_bit_cast(float4, a[i][0]), __builtin_bit_cast(float4, a[i][1]), a[i][0], a[i][1], a[i][2]);
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < KPW; ++i)
@@ -419,7 +422,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
         a[i][pl] = *reinterpret_cast<const bf16x8*>(p.A + pl * p.a_plane_stride + ((long)(kt0 + i) * 64 + alane) * 8);
   }
   bf16x8* my = reinterpret_cast<bf16x8*>(smem_raw + g16_smem(NW)) + (long)w * 2 * KPW * 64 + lane;     // ALDS: [plane - 1][i][lane]
-  if constexpr (ALDS) {
+  // ALDS_LATE (the 16-row persistent form): split and LDS stores wait for the image, so they sit BEHIND the first weight request
+  // (batch 8 +0.9 %).  Not in the z-form: there the same move costs qkv / cq 0.9 us at 32 rows (profiles/r03_early_wait_ab.txt)
+  if constexpr (ALDS && !ALDS_LATE) {
 #pragma unroll
     for (int i = 0; i < KPW; ++i) { my[i * 64] = a[i][1]; my[(KPW + i) * 64] = a[i][2]; }
   }
@@ -472,6 +477,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   __builtin_amdgcn_sched_barrier(0);
   load_strip(b0, blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (ALDS_LATE) {
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+      if constexpr (AF32) split3x8(__builtin_bit_cast(float4, a[i][0]), __builtin_bit_cast(float4, a[i][1]), a[i][0], a[i][1], a[i][2]);
+      my[i * 64] = a[i][1]; my[(KPW + i) * 64] = a[i][2];
+    }
+  }
   STAMP(1);
   {
     float s0 = 0.f;
@@ -869,11 +881,13 @@ __global__ __launch_bounds__(1024) void k_gemv_diag(GemmK p) {
 // KPW = 8 (K = 2048 per workgroup) or 4 (K = 1024: the encoder's shapes); AF32 = fp32 activation tiles in and out with the 512-thread
 // tail (decode), else planes in and out with the 32-threads-per-tile tail through the shared epilogue (every epilogue incl. CROSSKV and
 // the compaction maps: the short-prompt prefill, 33..128 rows).
-constexpr size_t g2t_smem(int kpw) { return (size_t)2 * 8 * kpw * 64 * 16 + sizeof(f32x4) * 2 * 8 * 64 + 2 * 1024 + sizeof(float) * 32; }
-template <int KPW, bool AF32, bool SPLITK>
-__global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
+// NW = 4 (planes, K = 1024 as 4 waves x 8 k-tiles, 256 threads, 74 KB of LDS): TWO workgroups per CU — the planes tail is 32 threads
+// per tile between two barriers, and with one workgroup per CU nothing else runs meanwhile (13.9 us per launch at 98 rows for 8-17 MB).
+constexpr size_t g2t_smem(int kpw, int nw = 8) { return (size_t)2 * nw * kpw * 64 * 16 + sizeof(f32x4) * 2 * nw * 64 + 2 * 1024 + sizeof(float) * 32; }
+template <int KPW, bool AF32, bool SPLITK, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
                                                int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
-  constexpr int NW = 8;
+  static_assert(NW == 8 || (NW == 4 && !AF32 && !SPLITK), "the 256-thread form serves the planes path without split-K");
   p.A = a_A; p.a_plane_stride = a_aps; p.W = a_W; p.KT = a_KT; p.M = a_M; p.epi = a_epi; p.nstrips = a_nstrips;
   p.out = a_out; p.ldo = a_ldo; p.gnext = a_gnext;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -992,8 +1006,37 @@ __global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps,
     gpre8[0] = ga.x; gpre8[1] = ga.y; gpre8[2] = ga.z; gpre8[3] = ga.w;
     gpre8[4] = gb.x; gpre8[5] = gb.y; gpre8[6] = gb.z; gpre8[7] = gb.w;
   };
+  // CROSSKV: a thread finishes the SAME row for every strip its workgroup walks — utterance and text position are looked up once (inside the
+  // strip loop the chain row_b -> seg_off -> cos / sin was three dependent round trips per strip, 3.5 us per (strip, m-tile pair) unit),
+  // and the RoPE table entries of a strip are requested while the previous one is still being finished
+  // (compile-time off where K per workgroup is not 1024 — the encoder width, the only K a cross-K/V projection has: the host sends no other here)
+  const bool ckv = !AF32 && NW * KPW == 32 && p.epi == DIA_EPI_CROSSKV;
+  int ep_row = e_r;                                        // row handed to the shared epilogue: inside the m-tile, or (CROSSKV) the text position
+  bool ep_live = e_live;
+  if (ckv && e_thread) {
+    const int m = 16 * (mt0 + e_t) + e_r;
+    int b = p.kv_batch_index;
+    ep_row = m;
+    if (p.row_b) {
+      b = e_live ? p.row_b[m] : -1;
+      ep_live = b >= 0;
+      ep_row = ep_live ? m - p.seg_off[b] : 0;
+    }
+    pe.kv_batch_index = b;
+  }
+  if (ckv) { pe.row_b = nullptr; pe.seg_off = nullptr; }     // (workgroup-uniform: the pointers stay scalar)
+  auto load_cs = [&](int strip) {
+    int s = p.strip_map ? p.strip_map[strip] : strip;
+    if (p.kv_layer_strips > 0) s %= p.kv_layer_strips;
+    if (s < p.kv_heads * 8) {
+      const int o = ep_row * 64 + (s & 7) * 8 + e_half * 4;    // (int: scalar base + 32-bit offset, one VGPR less than a 64-bit address)
+      const float4 cc = *reinterpret_cast<const float4*>(p.cos_t + o), ss = *reinterpret_cast<const float4*>(p.sin_t + o);
+      xpre8[0] = cc.x; xpre8[1] = cc.y; xpre8[2] = cc.z; xpre8[3] = cc.w;
+      gpre8[0] = ss.x; gpre8[1] = ss.y; gpre8[2] = ss.z; gpre8[3] = ss.w;
+    }
+  };
   if constexpr (AF32) { if (resid) load_resid(blockIdx.x); }
-  else { if (resid && e_thread) load_resid8(blockIdx.x); }
+  else { if (resid && e_thread) load_resid8(blockIdx.x); if (ckv && e_thread) load_cs(blockIdx.x); }
   __builtin_amdgcn_sched_barrier(0);
   load_strip(b0, blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
@@ -1001,8 +1044,11 @@ __global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps,
 
   auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
     const int next = strip + G;
+#ifndef DIA_X2T_NOWLOAD
     load_strip(bn, DIA_PREFETCH_CLAMP(next, p.nstrips));       // unconditional: see k_gemv_small
+#endif
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#ifndef DIA_X2T_NOMFMA
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1012,15 +1058,25 @@ __global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps,
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t][i], bc[i], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, bc[i], acc[t], 0, 0, 0);
       }
+#else
+    acc[0][0] = __builtin_bit_cast(float, (int)bc[0][0]); acc[1][0] = __builtin_bit_cast(float, (int)bc[KPW - 1][0]);
+#endif
     red[(0 * NW + w) * 64 + lane] = acc[0];
     red[(1 * NW + w) * 64 + lane] = acc[1];
     lds_barrier();
     float v;
+    [[maybe_unused]] float v_t1 = 0.f;                      // NW == 4: 256 threads, every thread sums its element of BOTH tiles
     {
       const float* rf = reinterpret_cast<const float*>(red + ti * NW * 64) + (c16 + 16 * (r16 >> 2)) * 4 + (r16 & 3);
       v = rf[0];
 #pragma unroll
       for (int ww = 1; ww < NW; ++ww) v += rf[ww * 256];
+      if constexpr (NW == 4) {
+        const float* rg = rf + NW * 256;
+        v_t1 = rg[0];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) v_t1 += rg[ww * 256];
+      }
     }
     bool last = true;
     if constexpr (SPLITK) {
@@ -1063,12 +1119,15 @@ __global__ __launch_bounds__(512) void k_gemm2t(const bf16_raw* a_A, long a_aps,
     if constexpr (!AF32) {
       // planes / every epilogue: the finished tiles in LDS rows, 32 threads per tile run the shared epilogue
       if (last) stgf[ti * 256 + r16 * 16 + c16] = v;
+      if constexpr (NW == 4) stgf[256 + r16 * 16 + c16] = v_t1;
       lds_barrier();
       if (e_thread) {
         const int n0 = strip * 16 + e_half * 8;
-        const int mrow = (p.epi == DIA_EPI_CROSSKV ? 16 * (mt0 + e_t) : 0) + e_r;
-        if (last) run_epilogue(p.epi == DIA_EPI_CROSSKV ? p : pe, stgf + e_t * 256 + e_r * 16, inv_s[16 * e_t + e_r], mrow, n0, e_half, strip, e_live, xpre8, gpre8);
+#ifndef DIA_X2T_NOEPI
+        if (last) run_epilogue(pe, stgf + e_t * 256 + e_r * 16, inv_s[16 * e_t + e_r], ep_row, n0, e_half, strip, ep_live, xpre8, gpre8, ckv);
+#endif
         if (next < p.nstrips && resid) load_resid8(next);
+        if (next < p.nstrips && ckv) load_cs(next);
       }
       lds_barrier();
     } else if (!last) {
@@ -1550,6 +1609,7 @@ int dia_gemm_init() {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<4, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(4)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8, 4)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, false, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
@@ -1606,7 +1666,8 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
     return dia_fail(DIA_E_ARG, "dia_gemm: RESID_EMIT needs planes and ssq_out covering N");
   if ((a->epi == DIA_EPI_SWIGLU_EMIT) && (!a->P || a->p_ktiles * 32 < a->nstrips * 8))
     return dia_fail(DIA_E_ARG, "dia_gemm: SWIGLU_EMIT needs planes covering N/2");
-  if (a->epi == DIA_EPI_CROSSKV && (!a->kc || !a->vc || !a->cos_t || !a->sin_t || (!a->strip_map && a->nstrips != a->kv_heads * 16) || (!a->row_b && a->M > a->kv_cap) || (!a->row_b != !a->seg_off) || (a->kv_vblocked && a->kv_cap % 32 != 0)))
+  if (a->epi == DIA_EPI_CROSSKV && (!a->kc || !a->vc || !a->cos_t || !a->sin_t || (!a->strip_map && a->nstrips != a->kv_heads * 16 && !(a->kv_layer_strips == a->kv_heads * 16 && a->nstrips % (a->kv_heads * 16) == 0)) ||
+                                     a->kv_layer_strips < 0 || (a->kv_layer_strips > 0 && (a->kv_layer_strips != a->kv_heads * 16 || a->kv_layer_stride <= 0)) || (!a->row_b && a->M > a->kv_cap) || (!a->row_b != !a->seg_off) || (a->kv_vblocked && a->kv_cap % 32 != 0)))
     return dia_fail(DIA_E_ARG, "dia_gemm: CROSSKV shape mismatch");
   if (a->epi < 0 || a->epi > DIA_EPI_CROSSKV) return dia_fail(DIA_E_ARG, "dia_gemm: unknown epilogue");
   if (a->ssq_in && a->ssq_ld < ((a->M + 15) / 16) * 16) return dia_fail(DIA_E_ARG, "dia_gemm: ssq_ld smaller than padded rows");
@@ -1690,21 +1751,26 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
                        (sk == 1 || a->sk_scratch_floats >= (int64_t)((mtiles + 1) / 2) * a->nstrips * sk * 512);
     const bool decode_ok = f32io && fast_epi && !a->cmap && !a->strip_map &&
                            (a->nstrips >= 1024 || (a->nstrips >= 512 && mtiles >= 3) || sk > 1 || dia_tune(DIA_TUNE_GEMM_2T) == 2);
-    const bool prefill_ok = planes && mtiles >= 3 && (fast_epi || a->epi == DIA_EPI_CROSSKV) && !(ktw == 32 && sk > 1);
+    const bool prefill_ok = planes && mtiles >= 3 && (fast_epi || (a->epi == DIA_EPI_CROSSKV && ktw == 32)) && !(ktw == 32 && sk > 1);
     if (shape && (decode_ok || prefill_ok) && dia_tune(DIA_TUNE_GEMM_2T) != 0) {
       const int zp = (mtiles + 1) / 2;
-      int per = 256 / zp / sk;
+      const bool half = !f32io && ktw == 32 && dia_tune(DIA_TUNE_GEMM_2T) != 3;     // K = 1024: 256-thread workgroups, two per CU (knob 3: the 512-thread form)
+      int budget = half ? 512 : 256;
+      if (!f32io && dia_tune(DIA_TUNE_G2T_WGS) > 0) budget = dia_tune(DIA_TUNE_G2T_WGS);
+      int per = budget / zp / sk;
       per = per >= 8 ? per / 8 * 8 : (per > 0 ? per : 1);
       const int spw_ = (a->nstrips + per - 1) / per;                                              // strips per workgroup
       int gx = (a->nstrips + spw_ - 1) / spw_;
       if (gx % 8 != 0 && (gx + 7) / 8 * 8 <= a->nstrips) gx = (gx + 7) / 8 * 8;                   // the pairs of one strip group on one XCD
-      const dim3 grid(gx, sk, zp), blk(512);
+      const dim3 grid(gx, sk, zp), blk(half ? 256 : 512);
       if (f32io) {
         if (sk > 1) launch_small_kernel<k_gemm2t<8, true, true>>(grid, blk, g2t_smem(8), st, k);
         else launch_small_kernel<k_gemm2t<8, true, false>>(grid, blk, g2t_smem(8), st, k);
       } else if (ktw == 64) {
         if (sk > 1) launch_small_kernel<k_gemm2t<8, false, true>>(grid, blk, g2t_smem(8), st, k);
         else launch_small_kernel<k_gemm2t<8, false, false>>(grid, blk, g2t_smem(8), st, k);
+      } else if (half) {
+        launch_small_kernel<k_gemm2t<8, false, false, 4>>(grid, blk, g2t_smem(8, 4), st, k);
       } else {
         launch_small_kernel<k_gemm2t<4, false, false>>(grid, blk, g2t_smem(4), st, k);
       }

@@ -59,6 +59,7 @@ struct GemmK {
   int mz;                                  // host side only: m-tiles a k_gemm16 launch covers through gridDim.z (0/1 = one)
   int a_f32, p_f32;                        // A / P are fp32 activation tiles (common.hpp) instead of three bf16 planes
   long kv_plane_stride;                    // CROSSKV, DIA_KV_BF16X2
+  long kv_layer_stride; int kv_layer_strips;   // CROSSKV over several layers (dia_gemm_args)
   int w_planes; long w_plane_stride;       // k_gemm only: hi / mid / lo planes of fp32 weights, one tile set each
 };
 
@@ -133,8 +134,10 @@ __device__ __forceinline__ void prefetch_epilogue(const GemmK& p, int tid, int m
 }
 
 // One thread = one row x 8 consecutive columns of the finished 16x16 tile.
+// pre_cs (CROSSKV, K strips): xpre[0..3] / gpre[0..3] already hold cos / sin of (position m, pairs i0..i0+3) — callers that finish many strips
+// for the same row look the row up once and request the table entries a strip ahead (k_gemm2t)
 __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, float inv, int m, int n0, int half,
-                                             int strip, bool live, const float* xpre, const float* gpre) {
+                                             int strip, bool live, const float* xpre, const float* gpre, bool pre_cs = false) {
   // (n0 and strip are by-value copies: the compaction maps below redirect them)
   if (p.epi == DIA_EPI_SCALE_STORE) {
     if (!live) return;
@@ -173,6 +176,12 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
   } else {  // DIA_EPI_CROSSKV: strips [0, heads*8) hold K as RoPE pairs (d, d+64), the rest hold V
     if (!live) return;
     if (p.strip_map) strip = p.strip_map[strip];                  // compacted cross K/V: original strip index
+    long lofs = 0;                                                // several layers in one launch: this strip's layer
+    if (p.kv_layer_strips > 0) {
+      const int layer = strip / p.kv_layer_strips;
+      strip -= layer * p.kv_layer_strips;
+      lofs = (long)layer * p.kv_layer_stride;
+    }
     int kvb = p.kv_batch_index;
     if (p.row_b) {                                                // packed batch: row -> (utterance, position)
       kvb = p.row_b[m];
@@ -182,24 +191,24 @@ __device__ __forceinline__ void run_epilogue(const GemmK& p, const float* trow, 
     const int nk = p.kv_heads * 8;
     if (strip < nk) {
       const int head = strip >> 3, i0 = (strip & 7) * 8 + half * 4;
-      const long base = (((long)kvb * p.kv_heads + head) * p.kv_cap + m) * 128;
+      const long base = lofs + (((long)kvb * p.kv_heads + head) * p.kv_cap + m) * 128;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int i = i0 + t;
         const float x1 = trow[half * 8 + 2 * t] * inv, x2 = trow[half * 8 + 2 * t + 1] * inv;
-        const float c = p.cos_t[(long)m * 64 + i], s = p.sin_t[(long)m * 64 + i];
+        const float c = pre_cs ? xpre[t] : p.cos_t[(long)m * 64 + i], s = pre_cs ? gpre[t] : p.sin_t[(long)m * 64 + i];
         kv_store(p.kc, p.kv_dtype, base + i, x1 * c - x2 * s, p.kv_plane_stride);
         kv_store(p.kc, p.kv_dtype, base + i + 64, x1 * s + x2 * c, p.kv_plane_stride);
       }
     } else {
       const int sv = strip - nk, head = sv >> 3, d0 = (sv & 7) * 16 + half * 8;
       if (p.kv_vblocked) {      // [key/32][128 dims][32 keys] (MFMA attention reads 8 consecutive keys per lane)
-        const long hb = ((long)kvb * p.kv_heads + head) * p.kv_cap * 128;
+        const long hb = lofs + ((long)kvb * p.kv_heads + head) * p.kv_cap * 128;
         const long blk = hb + (long)(m >> 5) * 128 * 32 + (m & 31);
 #pragma unroll
         for (int j = 0; j < 8; ++j) kv_store(p.vc, p.kv_dtype, blk + (long)(d0 + j) * 32, trow[half * 8 + j] * inv, p.kv_plane_stride);
       } else {
-        const long base = (((long)kvb * p.kv_heads + head) * p.kv_cap + m) * 128 + d0;
+        const long base = lofs + (((long)kvb * p.kv_heads + head) * p.kv_cap + m) * 128 + d0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) kv_store(p.vc, p.kv_dtype, base + j, trow[half * 8 + j] * inv, p.kv_plane_stride);
       }
@@ -366,6 +375,7 @@ inline int fill_gemmk(const dia_gemm_args* a, GemmK& k) {
   k.mz = 0;
   k.a_f32 = a->act_f32 & 1; k.p_f32 = (a->act_f32 >> 1) & 1;
   k.kv_plane_stride = a->kv_plane_stride;
+  k.kv_layer_strips = a->kv_layer_strips; k.kv_layer_stride = a->kv_layer_stride;
   k.w_planes = a->w_planes > 1 ? a->w_planes : 1; k.w_plane_stride = (long)a->KT * a->nstrips * 512;
   return DIA_OK;
 }

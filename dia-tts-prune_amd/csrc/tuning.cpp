@@ -7,9 +7,9 @@
 #include <string>
 
 static const char* const k_names[DIA_TUNE_COUNT] = {
-    "attn_nz", "attn_gpw", "attn_gpw_cross", "gemm_spw", "gemm_mz_max", "tile_min_blocks", "wo_sk", "wo_pair", "wo_nw", "wo_spw", "act_f32", "wo_diag", "gemm_2t", "gemm_zr", "seg", "seg_nb", "seg_dbg", "seg_sleep",
+    "attn_nz", "attn_gpw", "attn_gpw_cross", "gemm_spw", "gemm_mz_max", "tile_min_blocks", "wo_sk", "wo_pair", "wo_nw", "wo_spw", "act_f32", "wo_diag", "gemm_2t", "gemm_zr", "seg", "seg_nb", "seg_dbg", "seg_sleep", "g2t_wgs", "ckv_merge",
     "mlp_fuse", "tile_v", "blk32_kr", "blk32_ws", "no_g32", "g32_all", "g32m"};
-static int g_tune[DIA_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static int g_tune[DIA_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 int dia_tune(int id) { return (id >= 0 && id < DIA_TUNE_COUNT) ? g_tune[id] : -1; }
 

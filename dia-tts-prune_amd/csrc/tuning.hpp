@@ -26,6 +26,8 @@ enum dia_tune_id {
   DIA_TUNE_SEG_NB,             // seg_nb: 16 KiB weight slots each streaming wave of dia_seg_mlp keeps in flight (1..3)
   DIA_TUNE_SEG_DBG,            // seg_dbg: debug bits of dia_seg_mlp (1 = no weight loads: hand-off timing only, wrong results)
   DIA_TUNE_SEG_SLEEP,          // seg_sleep: s_sleep units before the first loads of the waves that stream the later ops
+  DIA_TUNE_G2T_WGS,            // g2t_wgs: workgroup budget of a k_gemm2t launch over planes (the short-prompt prefill); unset = see dia_gemm
+  DIA_TUNE_CKV_MERGE,          // ckv_merge: 0 = the prefill projects cross K/V with one launch per decoder layer (read by dia_hip/engine.py; A/B)
   // ---- EXPERIMENTS=1 builds only
   DIA_TUNE_MLP_FUSE,           // mlp_fuse: 1 = wi + wo as one persistent launch at batch 1 (dia_mlp_fused)
   DIA_TUNE_TILE_V,             // tile_v: prefill tile kernel variant (0..5; 3 = wave-specialised default)

@@ -46,7 +46,7 @@ class GemmArgs(C.Structure):
         ("row_b", C.c_void_p), ("seg_off", C.c_void_p), ("sk_scratch_floats", C.c_int64),
         ("sp_blocks", C.c_void_p), ("sp_toff", C.c_void_p),
         ("act_f32", C.c_int32), ("w_planes", C.c_int32), ("kv_plane_stride", C.c_int64),
-        ("w_layout", C.c_int32), ("_pad2", C.c_int32),
+        ("w_layout", C.c_int32), ("kv_layer_strips", C.c_int32), ("kv_layer_stride", C.c_int64),
     ]
 
 

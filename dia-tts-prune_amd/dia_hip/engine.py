@@ -211,8 +211,30 @@ class DeviceWeights:
         npos = max(cfg.data.audio_length, cfg.data.text_length) + 1
         cos, sin = lay.rope_tables(npos, HEAD_DIM, m.rope_min_timescale, m.rope_max_timescale)
         self.cos_t, self.sin_t = cos.to(device), sin.to(device)
+        # strip map of the merged cross-K/V launch of a compacted decoder: layer l's compact strip s -> l * (CH * 16) + original strip
+        self.smap_ckv_all = None
+        if any(L["smap_ckv"] is not None for L in self.dec_layers):
+            full = torch.arange(CH * 16, dtype=torch.int32, device=device)
+            self.smap_ckv_all = torch.cat([(L["smap_ckv"] if L["smap_ckv"] is not None else full) + i * CH * 16
+                                           for i, L in enumerate(self.dec_layers)]).to(torch.int32).contiguous()
         self.flat = None
         self.pack_flat()
+
+    def ckv_all(self) -> Optional[TiledW]:
+        """The cross-K/V tile sets of every decoder layer as ONE weight of sum(ns) strips, when they are one bf16 tile set each with
+        the same K and sit back to back in the arena (pack_flat); None otherwise (three-plane weights: one launch per layer)."""
+        ts = [L["ckv"] for L in self.dec_layers]
+        if self.weight_planes != 1 or not ts or any(t.kt != ts[0].kt for t in ts):
+            return None
+        p0 = ts[0].t.data_ptr()
+        for t in ts:
+            if t.t.data_ptr() != p0:
+                return None
+            p0 += t.nbytes
+        n = sum(t.t.numel() for t in ts)
+        base = ts[0].t
+        whole = torch.empty(0, dtype=base.dtype, device=base.device).set_(base.untyped_storage(), base.storage_offset(), (n,))
+        return TiledW(whole, ts[0].kt, sum(t.ns for t in ts))
 
     def tensors(self) -> List[torch.Tensor]:
         """Every device tensor of the model, in a deterministic order (the layout of the flat arena)."""
@@ -222,9 +244,14 @@ class DeviceWeights:
             out += [L[k] for k in ("cmap_mlp", "cmap_next") if L[k] is not None]
         out += [self.enc_norm, self.dec_emb]
         for L in self.dec_layers:
-            out += [L["g_sa"], L["g_ca"], L["g_mlp"]] + [L[k].t for k in ("qkv", "o", "cq", "co", "ckv", "wi", "wo")]
+            out += [L["g_sa"], L["g_ca"], L["g_mlp"]] + [L[k].t for k in ("qkv", "o", "cq", "co", "wi", "wo")]
             out += [L[k] for k in ("cmap_ca", "cmap_mlp", "cmap_next", "smap_qkv", "smap_cq", "smap_ckv", "hmap_self", "hmap_cross", "wo_diag")
                     if L.get(k) is not None]
+        # the cross-K/V projections of ALL layers back to back (whole KiB each, so the 256-byte slots leave no gaps): the prefill runs them
+        # as ONE GEMM over their common input (ckv_all)
+        out += [L["ckv"].t for L in self.dec_layers]
+        if self.smap_ckv_all is not None:
+            out.append(self.smap_ckv_all)
         out += [self.dec_norm, self.logits.t, self.cos_t, self.sin_t]
         out += [t for t in (self.cmap_first, self.enc_cmap_first) if t is not None]
         out += self.seg_layers
@@ -355,8 +382,12 @@ class DecodeSession:
         pl = (self.kv_planes,) if self.kv_planes > 1 else ()           # two-plane caches: [plane][...]
         self.k_self = [z(*pl, self.R, d.kv_heads, self.T, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
         self.v_self = [z(*pl, self.R, d.kv_heads, self.T, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
-        self.k_cross = [z(*pl, B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
-        self.v_cross = [z(*pl, B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt) for _ in range(d.n_layer)]
+        # cross caches of all layers in ONE allocation each (per-layer views): the prefill's merged cross-K/V launch addresses a layer
+        # as kc + layer * kv_layer_stride
+        self.k_cross_all = z(d.n_layer, *pl, B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt)
+        self.v_cross_all = z(d.n_layer, *pl, B, d.cross_query_heads, self.S, HEAD_DIM, dt=kvt)
+        self.k_cross = [self.k_cross_all[i] for i in range(d.n_layer)]
+        self.v_cross = [self.v_cross_all[i] for i in range(d.n_layer)]
         self.kv_plane_self = self.R * d.kv_heads * self.T * HEAD_DIM if self.kv_planes > 1 else 0
         self.kv_plane_cross = B * d.cross_query_heads * self.S * HEAD_DIM if self.kv_planes > 1 else 0
         self.text_len = torch.tensor(self.lens, dtype=torch.int32, device=dev)
@@ -590,7 +621,7 @@ class DecodeSession:
                                               ssq.data_ptr() + offs[b] * 4, Mp, hb.ptr(w.enc_cmap_first), st), "dia_embed_text")
 
                 def gemm(A, a_kt, W: TiledW, epi, *, M=Mp, a_ptr=None, ssq_ptr=None, ssq_in=False, out=None, ldo=0, gnext=None,
-                         P=None, p_kt=0, ssq_out=False, kv=None, strip_map=None, row_map=False, cmap=None, sk=0):
+                         P=None, p_kt=0, ssq_out=False, kv=None, strip_map=None, row_map=False, cmap=None, sk=0, kv_layers=None):
                     g = hb.GemmArgs()
                     g.A, g.a_plane_stride, g.a_ktiles, g.M = (a_ptr if a_ptr is not None else hb.ptr(A)), A[0].numel(), a_kt, M
                     g.W, g.KT, g.nstrips, g.epi = hb.ptr(W.t), W.kt, W.ns, epi
@@ -612,6 +643,8 @@ class DecodeSession:
                         g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = kv
                         g.kv_plane_stride = self.kv_plane_cross
                         g.cos_t, g.sin_t = hb.ptr(w.cos_t), hb.ptr(w.sin_t)
+                        if kv_layers is not None:
+                            g.kv_layer_strips, g.kv_layer_stride = kv_layers
                     if row_map:
                         g.row_b, g.seg_off = hb.ptr(row_b), hb.ptr(seg_off)
                     if sk > 1:      # split-K over workgroups through the session's slab scratch (short prompts: the z-form needs K <= 2048 per workgroup)
@@ -646,10 +679,16 @@ class DecodeSession:
                     gemm(ph, hkt, EL["wo"], hb.EPI_RESID_EMIT, out=x, ldo=E, gnext=gnext, P=px, p_kt=ekt, ssq_out=True,
                          cmap=EL["cmap_next"], sk=wo_sk)
                 # px now holds planes(x * encoder.norm.weight); ssq the row sums of squares of x
-                for i, DL in enumerate(w.dec_layers):
-                    gemm(px, ekt, DL["ckv"], hb.EPI_CROSSKV, ssq_in=True,
-                         kv=(hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i]), self.kv_code, d.cross_query_heads, self.S, 0),
-                         strip_map=DL["smap_ckv"], row_map=True)
+                ckv_all = w.ckv_all() if hb.get_tuning("ckv_merge") != 0 else None
+                if ckv_all is not None:             # ONE launch for the 18 layers: their input is the same (18 x 13.8 -> 1 x ~100 us at 98 rows)
+                    gemm(px, ekt, ckv_all, hb.EPI_CROSSKV, ssq_in=True,
+                         kv=(hb.ptr(self.k_cross_all), hb.ptr(self.v_cross_all), self.kv_code, d.cross_query_heads, self.S, 0),
+                         strip_map=w.smap_ckv_all, row_map=True, kv_layers=(d.cross_query_heads * 16, self.k_cross[0].numel()))
+                else:
+                    for i, DL in enumerate(w.dec_layers):
+                        gemm(px, ekt, DL["ckv"], hb.EPI_CROSSKV, ssq_in=True,
+                             kv=(hb.ptr(self.k_cross[i]), hb.ptr(self.v_cross[i]), self.kv_code, d.cross_query_heads, self.S, 0),
+                             strip_map=DL["smap_ckv"], row_map=True)
                 if keep_encoder_out:
                     for b in live:
                         Lb, o = self.lens[b], offs[b]

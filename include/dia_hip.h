@@ -144,7 +144,12 @@ typedef struct {
   int32_t w_layout;         /* 0: 16-column strips (above); 1: diagonal tiles of 4-column groups (dia_hip/layout.py diag_tile_weight): W = bf16
                              * [N/4][K/128][64][8], `nstrips` = N/8 (8-column half strips, one workgroup each, the whole K, no split-K);
                              * M <= 4, DIA_EPI_RESID_EMIT, fp32 tiles in and out; ssq_out receives N/8 partials per row */
-  int32_t _pad2;
+  /* CROSSKV for SEVERAL decoder layers in one launch (the prefill's cross-K/V projections share their input): kv_layer_strips > 0 =
+   * original strips per layer (kv_heads * 16); strip s (after strip_map, whose entries then count layer * kv_layer_strips + strip)
+   * belongs to layer s / kv_layer_strips and is written kv_layer_stride ELEMENTS behind kc / vc per layer.  W = the layers' tile
+   * sets back to back, nstrips = their sum.  0 = one layer (above). */
+  int32_t kv_layer_strips;
+  int64_t kv_layer_stride;
 } dia_gemm_args;
 int dia_gemm(const dia_gemm_args* a, void* stream);
 /* same launch, bracketed by dispatch-level start/stop events (hipExtLaunchKernelGGL); returns the
