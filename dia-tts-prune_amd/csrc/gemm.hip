@@ -884,10 +884,25 @@ __global__ __launch_bounds__(1024) void k_gemv_diag(GemmK p) {
 // NW = 4 (planes, K = 1024 as 4 waves x 8 k-tiles, 256 threads, 74 KB of LDS): TWO workgroups per CU — the planes tail is 32 threads
 // per tile between two barriers, and with one workgroup per CU nothing else runs meanwhile (13.9 us per launch at 98 rows for 8-17 MB).
 constexpr size_t g2t_smem(int kpw, int nw = 8) { return (size_t)2 * nw * kpw * 64 * 16 + sizeof(f32x4) * 2 * nw * 64 + 2 * 1024 + sizeof(float) * 32; }
-template <int KPW, bool AF32, bool SPLITK, int NW = 8>
+// CKV (NW = 4, bf16 caches with the blocked V layout, no strip map): the cross-K/V tail on ALL 256 threads with UNCONDITIONAL stores.  vmcnt counts
+// stores as well as loads and retires in order; the wait before a strip's first MFMA is one static count for every wave, so it is the
+// count of the path that issued the FEWEST memory operations since the awaited load — with the tail on two of the waves (or behind
+// `if (live)`) those waves sat out the acknowledgement of their 16 scattered 2-byte stores before every strip: 2 us per strip,
+// 138 us for the merged launch of the 18 layers where the same GEMM with a plain fp32 store takes 63.  Here every thread of every
+// wave issues the same two stores (rows past the end or of padding: into a sink) and the same two table loads for the next strip.
+__device__ bf16_raw g_ckv_sink[1024];
+// EPI >= 0 (fp32 tiles, no split-K): the epilogue is a compile-time constant and its tail issues the SAME memory operations on every thread of every
+// wave (dead rows and idle threads store into g_sink16, the next strip's residual is requested on a clamped index) — for the reason above: behind
+// run-time branches (`if (live)`, `if (tid < 128)`, the epilogue kind) the one static wait in front of the next strip's MFMAs is the count of the
+// emptiest path, and every wave that did store sits out the acknowledgement of its stores.  EPI = -1: the epilogue kind at run time (planes, split-K).
+__device__ float4 g_sink16[1024];
+template <int KPW, bool AF32, bool SPLITK, int NW = 8, bool CKV = false, int EPI = -1>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
                                                int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
   static_assert(NW == 8 || (NW == 4 && !AF32 && !SPLITK), "the 256-thread form serves the planes path without split-K");
+  static_assert(!CKV || (NW == 4 && KPW == 8), "the all-thread cross-K/V tail belongs to the 256-thread form");
+  static_assert(EPI < 0 || (!SPLITK && !CKV && (NW == 8 || (!AF32 && EPI != DIA_EPI_RESID_EMIT))), "the uniform tails: no split-K; 256 threads only for planes without the residual");
+  const int epi = EPI >= 0 ? EPI : a_epi;
   p.A = a_A; p.a_plane_stride = a_aps; p.W = a_W; p.KT = a_KT; p.M = a_M; p.epi = a_epi; p.nstrips = a_nstrips;
   p.out = a_out; p.ldo = a_ldo; p.gnext = a_gnext;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -977,7 +992,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
   const int rl = 16 * ti + r16;                            // row inside the workgroup's 32
   const bool live = rl < Ml;
   const long grow = 16 * mt0 + rl;                         // row of the whole batch
-  const bool resid = p.epi == DIA_EPI_RESID_EMIT;
+  const bool resid = epi == DIA_EPI_RESID_EMIT;
   float xpre1 = 0.f, gpre1 = 1.f;
   auto load_resid = [&](int strip) {
     const int n = strip * 16 + c16;
@@ -1035,7 +1050,37 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
       gpre8[0] = ss.x; gpre8[1] = ss.y; gpre8[2] = ss.z; gpre8[3] = ss.w;
     }
   };
-  if constexpr (AF32) { if (resid) load_resid(blockIdx.x); }
+  // CKV: thread (tile tt, u) finishes, for a K strip, RoPE pair u & 7 of row u >> 3 (8 threads = 16 contiguous bytes of a cache row, and
+  // again 64 elements further); for a V strip, columns u >> 4 and 8 + (u >> 4) of row u & 15 (16 threads = 32 contiguous bytes of the
+  // blocked layout).  Both rows are looked up once.
+  [[maybe_unused]] const int ck_tt = tid >> 7, ck_rK = (tid & 127) >> 3, ck_t8 = tid & 7, ck_rV = tid & 15, ck_cV = (tid & 127) >> 4;
+  [[maybe_unused]] int ck_posK = 0, ck_posV = 0;
+  [[maybe_unused]] long ck_baseK = 0, ck_baseV = 0;
+  [[maybe_unused]] bool ck_liveK = false, ck_liveV = false;
+  [[maybe_unused]] float ck_c = 0.f, ck_s = 0.f;
+  if constexpr (CKV) {
+    auto look = [&](int r, int& pos, bool& lv, long& base) {
+      const int rl_ = 16 * ck_tt + r, m = 16 * mt0 + rl_;
+      int b = p.kv_batch_index;
+      pos = m; lv = rl_ < Ml;
+      if (p.row_b) {
+        b = lv ? p.row_b[m] : -1;
+        lv = b >= 0;
+        pos = lv ? m - p.seg_off[b] : 0;
+      }
+      base = (long)(lv ? b : 0) * p.kv_heads * p.kv_cap * 128;
+    };
+    look(ck_rK, ck_posK, ck_liveK, ck_baseK);
+    look(ck_rV, ck_posV, ck_liveV, ck_baseV);
+  }
+  auto load_cs_all = [&](int strip) {                       // unconditional (a V strip loads two entries nobody reads)
+    int s = strip;
+    if (p.kv_layer_strips > 0) s %= p.kv_layer_strips;
+    const int o = ck_posK * 64 + (s & 7) * 8 + ck_t8;
+    ck_c = p.cos_t[o]; ck_s = p.sin_t[o];
+  };
+  if constexpr (CKV) load_cs_all(blockIdx.x);
+  else if constexpr (AF32 || EPI >= 0) { if (resid) load_resid(blockIdx.x); }
   else { if (resid && e_thread) load_resid8(blockIdx.x); if (ckv && e_thread) load_cs(blockIdx.x); }
   __builtin_amdgcn_sched_barrier(0);
   load_strip(b0, blockIdx.x);
@@ -1046,6 +1091,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
     const int next = strip + G;
 #ifndef DIA_X2T_NOWLOAD
     load_strip(bn, DIA_PREFETCH_CLAMP(next, p.nstrips));       // unconditional: see k_gemv_small
+#endif
+#ifndef DIA_X2T_NOPIN
+    // without this the scheduler sinks the requests behind the MFMAs they are meant to run under (both weight buffers live across the MFMA
+    // block is what the register budget was drawn for).  Only where it fits: the other instantiations spill 2..34 VGPRs when pinned
+    if constexpr (EPI >= 0 || CKV) __builtin_amdgcn_sched_barrier(0);
 #endif
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #ifndef DIA_X2T_NOMFMA
@@ -1116,7 +1166,109 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
       }
       lds_barrier();                                        // stgf is staged again below; red is free
     }
-    if constexpr (!AF32) {
+    if constexpr (CKV) {
+      stgf[r16 * 16 + c16] = v;
+      stgf[256 + r16 * 16 + c16] = v_t1;
+      lds_barrier();
+      {
+        int s = strip;
+        long lofs = 0;
+        if (p.kv_layer_strips > 0) {
+          const int layer = s / p.kv_layer_strips;
+          s -= layer * p.kv_layer_strips;
+          lofs = (long)layer * p.kv_layer_stride;
+        }
+        const int nk = p.kv_heads * 8;
+        bf16_raw *d0, *d1;
+        float o0, o1;
+        bool lv;
+        if (s < nk) {                                         // K: RoPE pair (i, i + 64) of one row  (run_epilogue's arithmetic)
+          const int head = s >> 3, i = (s & 7) * 8 + ck_t8;
+          const float inv = inv_s[16 * ck_tt + ck_rK];
+          const float* tr = stgf + ck_tt * 256 + ck_rK * 16 + 2 * ck_t8;
+          const float x1 = tr[0] * inv, x2 = tr[1] * inv;
+          o0 = x1 * ck_c - x2 * ck_s; o1 = x1 * ck_s + x2 * ck_c;
+          d0 = reinterpret_cast<bf16_raw*>(p.kc) + lofs + ck_baseK + ((long)head * p.kv_cap + ck_posK) * 128 + i;
+          d1 = d0 + 64;
+          lv = ck_liveK;
+        } else {                                              // V, blocked [key / 32][128 dims][32 keys]
+          const int sv = s - nk, head = sv >> 3, dd = (sv & 7) * 16 + ck_cV;
+          const float inv = inv_s[16 * ck_tt + ck_rV];
+          const float* tr = stgf + ck_tt * 256 + ck_rV * 16 + ck_cV;
+          o0 = tr[0] * inv; o1 = tr[8] * inv;
+          d0 = reinterpret_cast<bf16_raw*>(p.vc) + lofs + ck_baseV + (long)head * p.kv_cap * 128 + (long)(ck_posV >> 5) * 4096 + (ck_posV & 31) + dd * 32;
+          d1 = d0 + 8 * 32;
+          lv = ck_liveV;
+        }
+        if (!lv) { d0 = g_ckv_sink + tid; d1 = g_ckv_sink + 512 + tid; }
+        KVElem<bf16_raw>::store(d0, o0);
+        KVElem<bf16_raw>::store(d1, o1);
+      }
+      load_cs_all(DIA_PREFETCH_CLAMP(next, p.nstrips));
+      lds_barrier();                                          // the staging area is rewritten by the next strip
+    } else if constexpr (!AF32 && EPI >= 0) {
+      // planes out, compile-time epilogue: element-per-thread arithmetic (256 threads: one element of EACH tile), then ONE 16-byte plane
+      // fragment per thread — every thread of every wave issues the same stores (idle ones into the sink), see EPI above
+      constexpr int NE = NW == 8 ? 1 : 2;
+      float* const sinkf = reinterpret_cast<float*>(g_sink16);
+      const float vv[2] = {v, v_t1};
+      if constexpr (EPI == DIA_EPI_SCALE_STORE) {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          const int rlj = NW == 8 ? rl : 16 * j + r16;
+          float* dst = rlj < Ml ? p.out + (long)(16 * mt0 + rlj) * p.ldo + strip * 16 + c16 : sinkf + tid + 512 * j;
+          *dst = vv[j] * inv_s[rlj];
+        }
+        lds_barrier();                                        // red is rewritten by the next strip
+      } else {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          const int te = NW == 8 ? ti : j, rlj = 16 * te + r16;
+          float e;
+          if constexpr (EPI == DIA_EPI_RESID_EMIT) {           // (NW == 8: one element per thread)
+            const int n = strip * 16 + c16;
+            const float xv = xpre1 + vv[j];
+            float* dst = live ? p.out + grow * p.ldo + n : sinkf + tid;
+            *dst = xv;
+            const float sqv = mul_rn(xv, xv);
+            float accs = sqv;
+#pragma unroll
+            for (int jj = 1; jj < 8; ++jj) {
+              const float t = DIA_ROW_SHR(accs, 1);
+              if ((c16 & 7) == jj) accs = add_rn(t, sqv);
+            }
+            const float h0 = DIA_ROW_SHR(accs, 8);
+            float* sd = (live && c16 == 15) ? p.ssq_out + (long)strip * p.ssq_ld + grow : sinkf + 512 + tid;
+            *sd = h0 + accs;
+            e = mul_rn(xv, gpre1);
+          } else {                                            // SWIGLU: columns 0..7 gate, 8..15 up
+            const float up_raw = DIA_ROW_SHL(vv[j], 8);
+            const float inv = inv_s[rlj];
+            const float g = vv[j] * inv, u = up_raw * inv;
+            e = (g / (1.0f + expf(-g))) * u;
+          }
+          stgf[te * 256 + r16 * 16 + c16] = e;
+        }
+        lds_barrier();                                        // (also: red is free again)
+        {
+          // RESID: 2 tiles x 16 rows x 2 halves x 3 planes = 192 fragments; SWIGLU: 2 x 16 x 3 = 96 (8 outputs per row and strip)
+          constexpr bool RS_ = EPI == DIA_EPI_RESID_EMIT;
+          const int pl = RS_ ? tid >> 6 : tid >> 5;
+          const int tt = RS_ ? (tid >> 5) & 1 : (tid >> 4) & 1, mm = RS_ ? (tid >> 1) & 15 : tid & 15, hf = RS_ ? tid & 1 : 0;
+          const bool on = pl < 3 && 16 * tt + mm < Ml;
+          const float* src = &stgf[tt * 256 + mm * 16 + hf * 8];
+          bf16x8 h, mi, lo;
+          split3x8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4), h, mi, lo);
+          const bf16x8 frag = pl == 0 ? h : (pl == 1 ? mi : lo);
+          bf16_raw* Pt = p.P + (long)min(pl, 2) * p.p_plane_stride + (long)(mt0 + tt) * p.p_ktiles * 512;
+          bf16x8* dst = on ? reinterpret_cast<bf16x8*>(Pt + plane_frag_off(mm, RS_ ? strip * 16 + hf * 8 : strip * 8, p.p_ktiles))
+                           : reinterpret_cast<bf16x8*>(g_sink16 + tid);
+          *dst = frag;
+        }
+        if constexpr (EPI == DIA_EPI_RESID_EMIT) load_resid(DIA_PREFETCH_CLAMP(next, p.nstrips));
+        lds_barrier();                                        // the staging area is rewritten by the next strip
+      }
+    } else if constexpr (!AF32) {
       // planes / every epilogue: the finished tiles in LDS rows, 32 threads per tile run the shared epilogue
       if (last) stgf[ti * 256 + r16 * 16 + c16] = v;
       if constexpr (NW == 4) stgf[256 + r16 * 16 + c16] = v_t1;
@@ -1130,6 +1282,60 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
         if (next < p.nstrips && ckv) load_cs(next);
       }
       lds_barrier();
+    } else if constexpr (EPI >= 0) {
+      float* const sinkf = reinterpret_cast<float*>(g_sink16);
+      if constexpr (EPI == DIA_EPI_SCALE_STORE) {
+        float* dst = live ? p.out + grow * p.ldo + strip * 16 + c16 : sinkf + tid;
+        *dst = v * inv_s[rl];
+        lds_barrier();                                        // red is rewritten by the next strip
+      } else {
+        float e;
+        if constexpr (EPI == DIA_EPI_RESID_EMIT) {
+          const int n = strip * 16 + c16;
+          const float xv = xpre1 + v;
+          float* dst = live ? p.out + grow * p.ldo + n : sinkf + tid;
+          *dst = xv;
+          const float sqv = mul_rn(xv, xv);
+          float accs = sqv;
+#pragma unroll
+          for (int j = 1; j < 8; ++j) {
+            const float t = DIA_ROW_SHR(accs, 1);
+            if ((c16 & 7) == j) accs = add_rn(t, sqv);
+          }
+          const float h0 = DIA_ROW_SHR(accs, 8);
+          float* sd = (live && c16 == 15) ? p.ssq_out + (long)strip * p.ssq_ld + grow : sinkf + 512 + tid;
+          *sd = h0 + accs;
+          e = mul_rn(xv, gpre1);
+        } else {                                              // SWIGLU: columns 0..7 gate, 8..15 up
+          const float up_raw = DIA_ROW_SHL(v, 8);
+          const float inv = inv_s[rl];
+          const float g = v * inv, u = up_raw * inv;
+          e = (g / (1.0f + expf(-g))) * u;
+        }
+        stgf[ti * 256 + r16 * 16 + c16] = e;
+        lds_barrier();                                        // (also: red is free again)
+        // 16-byte stores of the staged values: RESID 4 per row (64 threads per tile), SWIGLU 2 per row (32 threads per tile) — issued by ALL threads
+        {
+          const int tt = tid >> 6 & 1, u = tid & 63;
+          float* Pt = Pf + (long)(mt0 + tt) * p.p_ktiles * 512;
+          float4* dst;
+          const float* src;
+          if constexpr (EPI == DIA_EPI_RESID_EMIT) {
+            const int mm = u >> 2, q = u & 3;
+            const bool on = tid < 128 && 16 * tt + mm < Ml;
+            dst = on ? reinterpret_cast<float4*>(Pt + plane_frag_off(mm, strip * 16 + (q >> 1) * 8, p.p_ktiles) + (q & 1) * 4) : g_sink16 + tid;
+            src = &stgf[tt * 256 + mm * 16 + q * 4];
+          } else {
+            const int mm = (u >> 1) & 15, q = u & 1;
+            const bool on = tid < 128 && u < 32 && 16 * tt + mm < Ml;
+            dst = on ? reinterpret_cast<float4*>(Pt + plane_frag_off(mm, strip * 8, p.p_ktiles) + q * 4) : g_sink16 + tid;
+            src = &stgf[tt * 256 + mm * 16 + q * 4];
+          }
+          *dst = *reinterpret_cast<const float4*>(src);
+        }
+        if constexpr (EPI == DIA_EPI_RESID_EMIT) load_resid(DIA_PREFETCH_CLAMP(next, p.nstrips));
+        lds_barrier();                                        // the staging area is rewritten by the next strip
+      }
     } else if (!last) {
       if (next < p.nstrips && resid) load_resid(next);
     } else if (p.epi == DIA_EPI_SCALE_STORE) {
@@ -1605,11 +1811,18 @@ int dia_gemm_init() {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_diag<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv_diag<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, false, 8, false, DIA_EPI_SCALE_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, false, 8, false, DIA_EPI_RESID_EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, false, 8, false, DIA_EPI_SWIGLU_EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<4, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(4)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8, 4)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8, 4)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false, 4, false, DIA_EPI_SCALE_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8, 4)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false, 4, false, DIA_EPI_SWIGLU_EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8, 4)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false, 8, false, DIA_EPI_RESID_EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, false, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<8, 8, true, true, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(g16_smem(8) + g16_alds(8, 8))) != hipSuccess) rc = 1;
@@ -1763,12 +1976,25 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
       int gx = (a->nstrips + spw_ - 1) / spw_;
       if (gx % 8 != 0 && (gx + 7) / 8 * 8 <= a->nstrips) gx = (gx + 7) / 8 * 8;                   // the pairs of one strip group on one XCD
       const dim3 grid(gx, sk, zp), blk(half ? 256 : 512);
+      // planes with a compile-time epilogue and the all-thread tail: dense shapes only (no compaction maps), knob 5 = the shared tail (A/B)
+      const bool puni = !f32io && !a->cmap && !a->strip_map && (a->epi != DIA_EPI_RESID_EMIT || a->gnext) && dia_tune(DIA_TUNE_GEMM_2T) != 5;
       if (f32io) {
+        const bool uni = dia_tune(DIA_TUNE_GEMM_2T) != 5;      // (knob 5: the run-time epilogue, A/B)
         if (sk > 1) launch_small_kernel<k_gemm2t<8, true, true>>(grid, blk, g2t_smem(8), st, k);
+        else if (uni && a->epi == DIA_EPI_SCALE_STORE) launch_small_kernel<k_gemm2t<8, true, false, 8, false, DIA_EPI_SCALE_STORE>>(grid, blk, g2t_smem(8), st, k);
+        else if (uni && a->epi == DIA_EPI_RESID_EMIT) launch_small_kernel<k_gemm2t<8, true, false, 8, false, DIA_EPI_RESID_EMIT>>(grid, blk, g2t_smem(8), st, k);
+        else if (uni && a->epi == DIA_EPI_SWIGLU_EMIT) launch_small_kernel<k_gemm2t<8, true, false, 8, false, DIA_EPI_SWIGLU_EMIT>>(grid, blk, g2t_smem(8), st, k);
         else launch_small_kernel<k_gemm2t<8, true, false>>(grid, blk, g2t_smem(8), st, k);
       } else if (ktw == 64) {
         if (sk > 1) launch_small_kernel<k_gemm2t<8, false, true>>(grid, blk, g2t_smem(8), st, k);
+        else if (puni && a->epi == DIA_EPI_RESID_EMIT) launch_small_kernel<k_gemm2t<8, false, false, 8, false, DIA_EPI_RESID_EMIT>>(grid, blk, g2t_smem(8), st, k);
         else launch_small_kernel<k_gemm2t<8, false, false>>(grid, blk, g2t_smem(8), st, k);
+      } else if (half && a->epi == DIA_EPI_CROSSKV && a->kv_dtype == DIA_KV_BF16 && a->kv_vblocked && !a->strip_map && dia_tune(DIA_TUNE_GEMM_2T) != 4) {
+        launch_small_kernel<k_gemm2t<8, false, false, 4, true>>(grid, blk, g2t_smem(8, 4), st, k);    // (knob 4: the shared tail, A/B)
+      } else if (half && puni && a->epi == DIA_EPI_SCALE_STORE) {
+        launch_small_kernel<k_gemm2t<8, false, false, 4, false, DIA_EPI_SCALE_STORE>>(grid, blk, g2t_smem(8, 4), st, k);
+      } else if (half && puni && a->epi == DIA_EPI_SWIGLU_EMIT) {
+        launch_small_kernel<k_gemm2t<8, false, false, 4, false, DIA_EPI_SWIGLU_EMIT>>(grid, blk, g2t_smem(8, 4), st, k);
       } else if (half) {
         launch_small_kernel<k_gemm2t<8, false, false, 4>>(grid, blk, g2t_smem(8, 4), st, k);
       } else {
