@@ -1135,3 +1135,150 @@ def test_gemm_diagonal_layout_resid(M, K, D):
     # what it is not built for is refused
     g.epi = hb.EPI_SCALE_STORE
     assert hb.lib().dia_gemm(C.byref(g), None) == -1
+
+
+@pytest.mark.parametrize("M,K,N,epi,f32", [
+    # planes in and out (the short-prompt prefill): K = 1024 -> the 256-thread form, K = 2048 -> the 512-thread form
+    (98, 1024, 6144, "store", 0), (128, 1024, 8192, "swiglu", 0), (40, 1024, 1024, "swiglu", 0), (98, 2048, 1024, "resid", 0),
+    (128, 2048, 2048, "resid", 0),
+    # fp32 tiles in and out (the decode step at 33..128 rows)
+    (64, 2048, 9264, "store", 1), (128, 2048, 16384, "swiglu", 1), (48, 2048, 16384, "swiglu", 1), (100, 2048, 2048, "resid", 1)])
+def test_gemm2t_uniform_tails_equal_run_time_tails(M, K, N, epi, f32):
+    """k_gemm2t with a compile-time epilogue and stores issued by every thread (idle lanes into a sink) against the tails that
+    branch on the epilogue kind at run time (knob gemm_2t=5): same bits in out, ssq and the emitted activations"""
+    d = dev()
+    torch.manual_seed(M + K + N)
+    x_in = torch.randn(M, K, device=d) * 2
+    Npad = (N + 15) // 16 * 16
+    W = torch.zeros(K, Npad, device=d)
+    W[:, :N] = bf16r(torch.randn(K, N, device=d) * 0.03)
+    Wt, kt, ns = lay.tile_weight(W)
+    mpad = (M + 15) // 16 * 16
+    mt = mpad // 16
+    resid = epi == "resid"
+    D_out = Npad if resid else (Npad // 2 if epi == "swiglu" else 0)
+    pkt = (D_out + 31) // 32 if D_out else 1
+    gn = bf16r(1.0 + 0.1 * torch.randn(Npad, device=d))
+    ssq_in = strip_ssq(x_in, mpad) if not resid else None
+    x0 = torch.randn(mpad, Npad, device=d)
+    res = []
+    try:
+        for knob in (5, -1):
+            hb.set_tuning("gemm_2t", knob)
+            A = lay.pack_planes(x_in)
+            if f32:
+                A.view(torch.float32).reshape(-1)[: A[0].numel()] = lay.pack_f32_tiles(x_in).reshape(-1)
+            g = hb.GemmArgs()
+            g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+            g.W, g.KT, g.nstrips = hb.ptr(Wt), kt, ns
+            g.epi = {"resid": hb.EPI_RESID_EMIT, "swiglu": hb.EPI_SWIGLU_EMIT, "store": hb.EPI_SCALE_STORE}[epi]
+            g.act_f32 = 3 * f32
+            out = x0.clone() if resid else torch.zeros(mpad, Npad, device=d)
+            P = torch.full((3, mt, pkt, 64, 8), 7.0, dtype=torch.bfloat16, device=d)
+            ssq_o = torch.zeros(ns, mpad, device=d)
+            g.ssq_ld = mpad
+            if ssq_in is not None:
+                g.ssq_in, g.ssq_in_n, g.inv_d, g.eps = hb.ptr(ssq_in), ssq_in.shape[0], 1.0 / K, 1e-5
+            if epi != "swiglu":
+                g.out, g.ldo = hb.ptr(out), Npad
+            if resid:
+                g.gnext, g.ssq_out = hb.ptr(gn), hb.ptr(ssq_o)
+            if D_out:
+                g.P, g.p_plane_stride, g.p_ktiles = hb.ptr(P), P[0].numel(), pkt
+            hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+            torch.cuda.synchronize()
+            res.append((out.clone(), ssq_o.clone(), P.clone()))
+    finally:
+        hb.set_tuning("gemm_2t", -1)
+    (o0, s0, p0), (o1, s1, p1) = res
+    assert torch.equal(o0[:M], o1[:M]) and torch.equal(s0[:, :M], s1[:, :M])
+    if D_out:
+        un = (lambda P_: lay.unpack_f32_tiles(P_.view(torch.float32).reshape(-1)[: mt * pkt * 512].reshape(mt, pkt, 64, 8), mpad, pkt * 32)) if f32 \
+            else (lambda P_: lay.unpack_planes(P_, mpad, pkt * 32))
+        e0, e1 = un(p0)[:M, :D_out], un(p1)[:M, :D_out]
+        assert torch.equal(e0, e1) and e0.abs().max().item() > 0
+    # rows past M and the padding of the buffers are untouched by the sink stores
+    assert torch.equal(o1[M:], (x0 if resid else torch.zeros_like(x0))[M:])
+    if epi == "store":
+        xd = x_in.double()
+        ref = (xd @ W.double()) * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+        assert (o1[:M].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    elif resid:
+        ref = x0[:M].double() + x_in.double() @ W.double()
+        assert (o1[:M].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("kvd,lens", [("bf16", (98,)), ("bf16", (40, 0, 57)), ("f32", (70, 33))])
+def test_gemm_crosskv_layers_merged_equals_per_layer(kvd, lens):
+    """dia_gemm_args.kv_layer_strips / kv_layer_stride: the cross-K/V projections of several decoder layers as ONE launch over their common
+    input (tile sets back to back, caches of all layers in one allocation) write the bits of one launch per layer; bf16 + blocked V at
+    K = 1024 and 33..128 rows runs the all-thread tail (k_gemm2t<8, false, false, 4, true>), fp32 caches the shared epilogue"""
+    d = dev()
+    torch.manual_seed(11)
+    E, H, NL = 1024, 16, 3
+    B = len(lens)
+    offs, tot = [], 0
+    for Lb in lens:
+        offs.append(tot)
+        tot += (Lb + 31) // 32 * 32
+    Mp = tot
+    cap = 128
+    x = torch.randn(Mp, E, device=d)
+    rb = np.full((Mp,), -1, dtype=np.int32)
+    for b, Lb in enumerate(lens):
+        rb[offs[b]: offs[b] + Lb] = b
+    row_b = torch.from_numpy(rb).to(d)
+    seg_off = torch.tensor(offs, dtype=torch.int32, device=d)
+    perm = lay.rope_pair_perm(128).to(d)
+    tiles = []
+    for _ in range(NL):
+        wk = bf16r(torch.randn(E, H, 128, device=d) * 0.05)
+        wv = bf16r(torch.randn(E, H, 128, device=d) * 0.05)
+        Wt, kt, ns = lay.tile_weight(torch.cat([wk[:, :, perm].reshape(E, -1), wv.reshape(E, -1)], dim=1))
+        tiles.append(Wt)
+    W_all = torch.cat([t.reshape(-1) for t in tiles])
+    cos, sin = [t.to(d) for t in lay.rope_tables(cap + 1, 128, 1, 10000)]
+    kdt = torch.float32 if kvd == "f32" else torch.bfloat16
+    code = hb.KV_F32 if kvd == "f32" else hb.KV_BF16
+    blocked = int(kvd == "bf16")
+    A = lay.pack_planes(x)
+    ssq = strip_ssq(x, Mp)
+
+    def launch(Wptr, nstrips, kc, vc, layers):
+        g = hb.GemmArgs()
+        g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], Mp
+        g.W, g.KT, g.nstrips, g.epi = Wptr, kt, nstrips, hb.EPI_CROSSKV
+        g.ssq_in, g.ssq_in_n, g.inv_d, g.eps, g.ssq_ld = hb.ptr(ssq), E // 16, 1.0 / E, 1e-5, Mp
+        g.kc, g.vc, g.kv_dtype, g.kv_heads, g.kv_cap, g.kv_batch_index = hb.ptr(kc), hb.ptr(vc), code, H, cap, 0
+        g.cos_t, g.sin_t, g.kv_vblocked = hb.ptr(cos), hb.ptr(sin), blocked
+        g.row_b, g.seg_off = hb.ptr(row_b), hb.ptr(seg_off)
+        if layers:
+            g.kv_layer_strips, g.kv_layer_stride = H * 16, kc[0].numel()
+        hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+
+    k1 = torch.zeros(NL, B, H, cap, 128, dtype=kdt, device=d)
+    v1 = torch.zeros_like(k1)
+    k2, v2 = torch.zeros_like(k1), torch.zeros_like(k1)
+    for l in range(NL):
+        launch(hb.ptr(tiles[l]), ns, k1[l], v1[l], False)
+    launch(hb.ptr(W_all), NL * ns, k2, v2, True)
+    torch.cuda.synchronize()
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    assert k1.abs().max().item() > 0 and v1[NL - 1].abs().max().item() > 0
+    for b, Lb in enumerate(lens):                       # nothing behind an utterance's text
+        assert (k2[:, b, :, Lb:] == 0).all()
+    # and one layer against float64
+    xd = x.double()
+    h = xd * torch.rsqrt((xd ** 2).mean(-1, keepdim=True) + 1e-5)
+    Wl = lay.untile_weight(tiles[NL - 1], E, 2 * H * 128).double() if hasattr(lay, "untile_weight") else None
+    if Wl is not None:
+        inv = torch.argsort(perm)
+        kfull = (h @ Wl[:, : H * 128]).reshape(Mp, H, 128)[:, :, inv]
+        b0 = next(b for b, Lb in enumerate(lens) if Lb > 0)
+        rows = slice(offs[b0], offs[b0] + lens[b0])
+        c, s = cos[: lens[b0]].double()[:, None, :], sin[: lens[b0]].double()[:, None, :]
+        kk = kfull[rows]
+        kr = torch.cat([kk[..., :64] * c - kk[..., 64:] * s, kk[..., :64] * s + kk[..., 64:] * c], dim=-1)
+        got = k2[NL - 1, b0, :, : lens[b0]].double().transpose(0, 1)
+        tol = 2e-5 if kvd == "f32" else 1e-2
+        assert (got - kr).abs().max().item() <= tol * kr.abs().max().item()
