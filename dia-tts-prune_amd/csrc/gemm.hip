@@ -280,6 +280,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_small(const bf16_raw* a_A, lon
     // nobody reads): behind an `if` the wait before the first MFMA has to serve the path without the new loads too, the
     // compiler then emits vmcnt(KPW - 1 - i) instead of vmcnt(2 KPW - 1 - i) and every MFMA waits for the load just issued
     if constexpr (MULTI) load_strip(bn, DIA_PREFETCH_CLAMP(next, p.nstrips));
+#ifdef DIA_PIN_PREFETCH
+    if constexpr (MULTI) __builtin_amdgcn_sched_barrier(0);     // keep the requests IN FRONT of the MFMAs they are meant to run under
+#endif
     f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
@@ -501,6 +504,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
     auto body_z = [&](bf16x8* bc, bf16x8* bn, int strip) {
       const int next = strip + G;
       if constexpr (MULTI) load_strip(bn, DIA_PREFETCH_CLAMP(next, p.nstrips));     // unconditional: see k_gemv_small
+#ifdef DIA_PIN_PREFETCH
+      if constexpr (MULTI) __builtin_amdgcn_sched_barrier(0);     // keep the requests IN FRONT of the MFMAs they are meant to run under
+#endif
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int i = 0; i < KPW; ++i)
@@ -725,6 +731,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
   auto body = [&](bf16x8* bc, bf16x8* bn, int strip) {
     const int next = strip + G;
     if constexpr (MULTI) load_strip(bn, DIA_PREFETCH_CLAMP(strip + DIST * G, p.nstrips));       // unconditional: see k_gemv_small
+#ifdef DIA_PIN_PREFETCH
+    if constexpr (MULTI) __builtin_amdgcn_sched_barrier(0);     // keep the requests IN FRONT of the MFMAs they are meant to run under
+#endif
     f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < KPW; ++i)
@@ -1963,7 +1972,7 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
     const bool shape = (ktw == 64 || (planes && ktw == 32)) && a->KT % sk == 0 && a->w_planes <= 1 && mtiles >= 2 && mtiles <= mz_max &&
                        (sk == 1 || a->sk_scratch_floats >= (int64_t)((mtiles + 1) / 2) * a->nstrips * sk * 512);
     const bool decode_ok = f32io && fast_epi && !a->cmap && !a->strip_map &&
-                           (a->nstrips >= 1024 || (a->nstrips >= 512 && mtiles >= 3) || sk > 1 || dia_tune(DIA_TUNE_GEMM_2T) == 2);
+                           (a->nstrips >= 1024 || (a->nstrips >= 512 && mtiles >= 2) || mtiles >= 7 || sk > 1 || dia_tune(DIA_TUNE_GEMM_2T) == 2);     // (from 7 m-tiles on the 128..192-strip projections gain as well: batch 64 +1.4 %)
     const bool prefill_ok = planes && mtiles >= 3 && (fast_epi || (a->epi == DIA_EPI_CROSSKV && ktw == 32)) && !(ktw == 32 && sk > 1);
     if (shape && (decode_ok || prefill_ok) && dia_tune(DIA_TUNE_GEMM_2T) != 0) {
       const int zp = (mtiles + 1) / 2;
