@@ -196,3 +196,39 @@ def test_compaction_plan_from_zeros():
     assert int(cpt.pad_keep(k2).sum()) == 224             # small models: whole k-tiles only
     dense = cpt.plan_decoder_layer(sd, pre, d.gqa_query_heads, d.kv_heads, d.cross_query_heads)
     assert not cpt.is_pruned(dense)
+
+
+def test_cross_kv_tile_sets_are_one_weight_for_the_prefill():
+    """DeviceWeights.ckv_all(): the cross-K/V tile sets of all decoder layers sit back to back in the arena and are handed to the prefill as ONE
+    weight (dia_gemm_args.kv_layer_strips / kv_layer_stride); a compacted decoder brings the strip map of that merged launch; three-plane
+    weights keep one launch per layer"""
+    from dia_hip.engine import DeviceWeights
+    from dia_hip.pruning import structured_prune_state_dict
+    cfg = C.mid_config()
+    d = cfg.model.decoder
+    cpu = torch.device("cpu")
+    sd = W.synthetic_state_dict(cfg, seed=7, std=0.02)
+    w = DeviceWeights(cfg, sd, cpu)
+    allw = w.ckv_all()
+    per = [L["ckv"] for L in w.dec_layers]
+    assert allw is not None and allw.kt == per[0].kt and allw.ns == sum(t.ns for t in per) == d.n_layer * d.cross_query_heads * 16
+    assert torch.equal(allw.t, torch.cat([t.t.reshape(-1) for t in per]))
+    assert allw.t.data_ptr() == per[0].t.data_ptr()                      # a view of the arena, not a copy
+    lo = w.flat.data_ptr()
+    assert lo <= allw.t.data_ptr() and allw.t.data_ptr() + allw.t.numel() * 2 <= lo + w.flat.numel()
+    assert w.smap_ckv_all is None
+    assert DeviceWeights(cfg, sd, cpu, weight_planes=3).ckv_all() is None
+    # structured-pruned checkpoint -> compacted decoder: merged strip map = layer * (heads * 16) + the layer's original strips
+    psd, _ = structured_prune_state_dict(cfg, sd, amount=0.5, dim=0, n=2)
+    wp = DeviceWeights(cfg, psd, cpu)
+    assert wp.compacted and wp.smap_ckv_all is not None and wp.smap_ckv_all.dtype == torch.int32
+    pa = wp.ckv_all()
+    assert pa is not None and pa.ns == wp.smap_ckv_all.numel() == sum(L["ckv"].ns for L in wp.dec_layers)
+    per_layer = d.cross_query_heads * 16
+    o = 0
+    for i, L in enumerate(wp.dec_layers):
+        seg = wp.smap_ckv_all[o: o + L["ckv"].ns]
+        o += L["ckv"].ns
+        assert (seg // per_layer == i).all()
+        if L["smap_ckv"] is not None:
+            assert torch.equal(seg - i * per_layer, L["smap_ckv"])
