@@ -156,9 +156,15 @@ def measure(w, cfg, *, batch, kv, steps, warmup, use_graph=True, seeds=None, dis
     prefill_s = time.time() - tp
     # second, warm pass bracketed by events on the session's stream: GPU-side prefill time (the first pass pays
     # module loading and allocator growth), for the MFMA utilisation of the prefill GEMMs (north star)
+    # The ~80 launches are queued BEHIND a device-side spin of a few milliseconds, so that the interval between the events is the GPU's own
+    # time whatever the host needs to enqueue them (0.5-0.8 ms from Python at batch 1 — as long as the GPU takes; reported beside it)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(sess.stream):
+        torch.cuda._sleep(int(8e6))
     ev0.record(sess.stream)
+    th = time.time()
     sess.prefill()
+    prefill_enqueue_s = time.time() - th
     ev1.record(sess.stream)
     sess.sync()
     prefill_gpu_s = ev0.elapsed_time(ev1) * 1e-3
@@ -168,12 +174,12 @@ def measure(w, cfg, *, batch, kv, steps, warmup, use_graph=True, seeds=None, dis
     attn_flops = e_.n_layer * e_.n_head * 4 * 128 * sum(l * l for l in sess.lens)
     prefill_flops = 2.0 * rows_ * prefill_params + attn_flops
     alg_tflops = prefill_flops / prefill_gpu_s / 1e12
-    prefill = {"text_bytes": rows_, "gpu_s": round(prefill_gpu_s, 5), "host_s_first_call": round(prefill_s, 4),
+    prefill = {"text_bytes": rows_, "gpu_s": round(prefill_gpu_s, 5), "host_enqueue_s": round(prefill_enqueue_s, 5), "host_s_first_call": round(prefill_s, 4),
                "algorithmic_tflop": round(prefill_flops / 1e12, 4), "achieved_tflops_algorithmic": round(alg_tflops, 1),
                "peak_tflops_bf16_dense": MFMA_PEAK_TFLOPS, "mfma_frac": round(alg_tflops / MFMA_PEAK_TFLOPS, 4),
                "mfma_frac_issued": round(3 * alg_tflops / MFMA_PEAK_TFLOPS, 4),
-               "note": "mfma_frac = ALGORITHMIC flops (2*rows*params + attention) / GPU time of the whole warm prefill pass incl. the launch "
-                       "gaps of its host-driven chain / 2.5 PFLOP/s; every product is fp32-exact = 3 bf16 MFMAs (hi/mid/lo activation "
+               "note": "gpu_s = events around the whole warm prefill pass, its launches queued behind a device-side spin (the GPU's own time); host_enqueue_s = "
+                       "what the Python host needed to enqueue them.  mfma_frac = ALGORITHMIC flops (2*rows*params + attention) / gpu_s / 2.5 PFLOP/s; every product is fp32-exact = 3 bf16 MFMAs (hi/mid/lo activation "
                        "plane x bf16 weight), so the matrix pipe issues 3x that (mfma_frac_issued)"}
 
     sess.ensure_noise(warmup + steps + profile_reps + 2)      # host RNG + upload stay outside the timed region

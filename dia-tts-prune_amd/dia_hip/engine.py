@@ -592,21 +592,39 @@ class DecodeSession:
                 ekt = E // 32
                 akt = max(max(1, Hmax * HEAD_DIM // 32), max(EL["o"].kt for EL in w.enc_layers))   # o rows may be zero-padded
                 hkt = max(EL["wo"].kt for EL in w.enc_layers)                 # (compacted) hidden width in k-tiles
-                z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)
-                x = z(Mp, E)
-                px, pa, ph = (z(3, mt, kt_, 64, 8, dt=torch.bfloat16) for kt_ in (ekt, akt, hkt))
-                ssq = z(E // 16, Mp)
+                # every buffer of the pass is a view of ONE zero-filled allocation (one memset instead of nine), every small integer
+                # table one host array (one copy instead of 3 + B): the chain is ~80 launches, each of these was one more
                 nq_max = 3 * Hmax * HEAD_DIM
-                qkv = z(Mp, nq_max)
-                kp = z(3, Hmax, Mp, HEAD_DIM, dt=torch.bfloat16)           # K / V planes of the attention (scratch)
-                vp = z(3, Hmax, Mp, HEAD_DIM, dt=torch.bfloat16)
-                rb = np.full((Mp,), -1, dtype=np.int32)
-                for b, Lb in enumerate(self.lens):
-                    rb[offs[b]: offs[b] + Lb] = b
-                row_b = torch.from_numpy(rb).to(dev)
-                seg_off = torch.tensor(offs, dtype=torch.int32, device=dev)
-                seg_len = torch.tensor(self.lens, dtype=torch.int32, device=dev)
+                shapes = [((Mp, E), torch.float32), ((3, mt, ekt, 64, 8), torch.bfloat16), ((3, mt, akt, 64, 8), torch.bfloat16),
+                          ((3, mt, hkt, 64, 8), torch.bfloat16), ((E // 16, Mp), torch.float32), ((Mp, nq_max), torch.float32),
+                          ((3, Hmax, Mp, HEAD_DIM), torch.bfloat16), ((3, Hmax, Mp, HEAD_DIM), torch.bfloat16)]
+                sizes = [_ceil(int(np.prod(sh)) * (4 if dt == torch.float32 else 2), 256) for sh, dt in shapes]
+                ws = torch.zeros(sum(sizes), dtype=torch.uint8, device=dev)
+                views, o_ = [], 0
+                for (sh, dt), nb in zip(shapes, sizes):
+                    n_el = int(np.prod(sh))
+                    views.append(ws[o_: o_ + n_el * (4 if dt == torch.float32 else 2)].view(dt).view(*sh))
+                    o_ += nb
+                x, px, pa, ph, ssq, qkv, kp, vp = views          # (kp / vp: K / V planes of the attention, scratch)
                 live = [b for b in range(self.B) if self.lens[b] > 0]
+                id_off, n_ids = {}, 0
+                for b in live:
+                    id_off[b] = n_ids
+                    n_ids += _ceil(self.lens[b], 4)                # (16-byte aligned runs)
+                tab = np.zeros((Mp + 2 * _ceil(self.B, 4) + n_ids,), dtype=np.int32)
+                tab[:Mp] = -1
+                for b, Lb in enumerate(self.lens):
+                    tab[offs[b]: offs[b] + Lb] = b
+                o_so, o_sl = Mp, Mp + _ceil(self.B, 4)
+                tab[o_so: o_so + self.B] = offs
+                tab[o_sl: o_sl + self.B] = self.lens
+                o_id = Mp + 2 * _ceil(self.B, 4)
+                for b in live:
+                    tab[o_id + id_off[b]: o_id + id_off[b] + self.lens[b]] = self.text_ids[b]
+                # pinned + asynchronous: a pageable copy blocks the host until the stream has drained, and every launch behind it starts late
+                self._pf_tab_host = torch.from_numpy(tab).pin_memory()        # (kept until the next prefill: the copy reads it in stream order)
+                tab_d = self._pf_tab_host.to(dev, non_blocking=True)
+                row_b, seg_off, seg_len = tab_d[:Mp], tab_d[o_so: o_so + self.B], tab_d[o_sl: o_sl + self.B]
 
                 def rows(t, b, width):              # device pointer of row off_b of a [Mp, width] fp32 buffer
                     return t.data_ptr() + offs[b] * width * 4
@@ -615,7 +633,7 @@ class DecodeSession:
                     return P.data_ptr() + (offs[b] // 16) * kt_ * 512 * 2
 
                 for b in live:
-                    ids = torch.from_numpy(self.text_ids[b]).to(dev)
+                    ids = tab_d[o_id + id_off[b]: o_id + id_off[b] + self.lens[b]]
                     hb.check(L.dia_embed_text(hb.ptr(ids), self.lens[b], hb.ptr(w.enc_emb), E, hb.ptr(w.enc_layers[0]["g_sa"]),
                                               rows(x, b, E), planes_at(px, b, ekt), px[0].numel(), ekt,
                                               ssq.data_ptr() + offs[b] * 4, Mp, hb.ptr(w.enc_cmap_first), st), "dia_embed_text")
