@@ -1138,7 +1138,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
       }
     }
     bool last = true;
+#ifdef DIA_X2T_NOHANDOFF
+    if constexpr (SPLITK) last = ks == SK - 1;               // TIMING ONLY: no slab, no ticket, no merge (wrong results)
+    if constexpr (false) {
+#else
     if constexpr (SPLITK) {
+#endif
       // both partial tiles leave together: one slab publication, one ticket, one merge by the last arriver in split order
       // (the protocol of splitk_combine: sc1 stores acknowledged before the ticket, sc1 loads after it; no fences)
       stgf[ti * 256 + r16 * 16 + c16] = v;
@@ -1162,8 +1167,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
       last = sk_flag != 0;
       if (last) {
         if (tid < 128) {
+          // SK <= 4 in every launch the hosts sends here: every slab requested before the first is used (the plain loop took them one
+          // coherent round trip at a time — 3 us on the workgroup that arrives last, a quarter of all units)
+          f32x4 sv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < SK) sv[k] = ld4_agent(sr, (int)(((unit * SK + k) * 512 + tt * 256 + row * 16 + c4) * 4));
           f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          for (int k = 0; k < SK; ++k) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < SK) { a[0] += sv[k][0]; a[1] += sv[k][1]; a[2] += sv[k][2]; a[3] += sv[k][3]; }
+          for (int k = 4; k < SK; ++k) {
             const f32x4 t = ld4_agent(sr, (int)(((unit * SK + k) * 512 + tt * 256 + row * 16 + c4) * 4));
             a[0] += t[0]; a[1] += t[1]; a[2] += t[2]; a[3] += t[3];
           }
