@@ -892,7 +892,7 @@ __global__ __launch_bounds__(1024) void k_gemv_diag(GemmK p) {
 // the compaction maps: the short-prompt prefill, 33..128 rows).
 // NW = 4 (planes, K = 1024 as 4 waves x 8 k-tiles, 256 threads, 74 KB of LDS): TWO workgroups per CU — the planes tail is 32 threads
 // per tile between two barriers, and with one workgroup per CU nothing else runs meanwhile (13.9 us per launch at 98 rows for 8-17 MB).
-constexpr size_t g2t_smem(int kpw, int nw = 8) { return (size_t)2 * nw * kpw * 64 * 16 + sizeof(f32x4) * 2 * nw * 64 + 2 * 1024 + sizeof(float) * 32; }
+constexpr size_t g2t_smem(int kpw, int nw = 8, bool sk2 = false) { return (size_t)2 * nw * kpw * 64 * 16 + sizeof(f32x4) * 2 * nw * 64 + 2 * 1024 + sizeof(float) * 32 + (sk2 ? 4096 : 0); }
 // CKV (NW = 4, bf16 caches with the blocked V layout, no strip map): the cross-K/V tail on ALL 256 threads with UNCONDITIONAL stores.  vmcnt counts
 // stores as well as loads and retires in order; the wait before a strip's first MFMA is one static count for every wave, so it is the
 // count of the path that issued the FEWEST memory operations since the awaited load — with the tail on two of the waves (or behind
@@ -905,12 +905,16 @@ __device__ bf16_raw g_ckv_sink[1024];
 // run-time branches (`if (live)`, `if (tid < 128)`, the epilogue kind) the one static wait in front of the next strip's MFMAs is the count of the
 // emptiest path, and every wave that did store sits out the acknowledgement of its stores.  EPI = -1: the epilogue kind at run time (planes, split-K).
 __device__ float4 g_sink16[1024];
-template <int KPW, bool AF32, bool SPLITK, int NW = 8, bool CKV = false, int EPI = -1>
+// SK2 (fp32 tiles, split-K, RESID_EMIT = wo at 17..128 rows): the hand-off of the K quarters once per PAIR of strips — four partial tiles, one slab
+// publication, one ticket, one merge.  A hand-off is two dependent coherent round trips (slab stores acknowledged, then the ticket) that nothing
+// overlaps: priced with a build that skips it, 13 of wo's 37 us at 128 rows (eight per workgroup).  Same slabs, same summation order: bit-identical.
+template <int KPW, bool AF32, bool SPLITK, int NW = 8, bool CKV = false, int EPI = -1, bool SK2 = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_raw* a_A, long a_aps, const bf16_raw* a_W, int a_KT, int a_M, int a_epi,
                                                int a_nstrips, float* a_out, int a_ldo, const float* a_gnext, GemmK p) {
   static_assert(NW == 8 || (NW == 4 && !AF32 && !SPLITK), "the 256-thread form serves the planes path without split-K");
   static_assert(!CKV || (NW == 4 && KPW == 8), "the all-thread cross-K/V tail belongs to the 256-thread form");
   static_assert(EPI < 0 || (!SPLITK && !CKV && (NW == 8 || (!AF32 && EPI != DIA_EPI_RESID_EMIT))), "the uniform tails: no split-K; 256 threads only for planes without the residual");
+  static_assert(!SK2 || (AF32 && SPLITK && NW == 8 && EPI < 0 && !CKV), "the strip-pair hand-off belongs to the split-K form over fp32 tiles");
   const int epi = EPI >= 0 ? EPI : a_epi;
   p.A = a_A; p.a_plane_stride = a_aps; p.W = a_W; p.KT = a_KT; p.M = a_M; p.epi = a_epi; p.nstrips = a_nstrips;
   p.out = a_out; p.ldo = a_ldo; p.gnext = a_gnext;
@@ -919,6 +923,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw + (size_t)2 * NW * KPW * 64 * 16);             // [2 tiles][NW][64]
   float* stgf = reinterpret_cast<float*>(smem_raw + (size_t)2 * NW * KPW * 64 * 16 + sizeof(f32x4) * 2 * NW * 64);   // [2 tiles][16][16]
   float* inv_s = stgf + 2 * 256;                                                               // [32]
+  [[maybe_unused]] float* m4 = inv_s + 32;                                                     // SK2: [2 strips][2 tiles][16][16]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int mtiles = (p.M + 15) >> 4;
   const int mt0 = 2 * blockIdx.z;                          // first m-tile of this workgroup
@@ -1415,6 +1420,111 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
   };
   lds_barrier();          // inv_s
   int strip = blockIdx.x;                                   // strip pairs, then at most one more (see k_gemv_small)
+  if constexpr (SK2) {
+    // weights x both tiles of one strip -> this thread's element of the K-quarter's partial tiles
+    auto mm = [&](bf16x8* bc, bf16x8* bn, int pre) -> float {
+      load_strip(bn, DIA_PREFETCH_CLAMP(pre, p.nstrips));
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+          const bf16x8 lo = my[(t * NW * KPW + i) * 64];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t][i], bc[i], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t][i], bc[i], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, bc[i], acc[t], 0, 0, 0);
+        }
+      red[(0 * NW + w) * 64 + lane] = acc[0];
+      red[(1 * NW + w) * 64 + lane] = acc[1];
+      lds_barrier();
+      const float* rf = reinterpret_cast<const float*>(red + ti * NW * 64) + (c16 + 16 * (r16 >> 2)) * 4 + (r16 & 3);
+      float v = rf[0];
+#pragma unroll
+      for (int ww = 1; ww < NW; ++ww) v += rf[ww * 256];
+      return v;
+    };
+    // RESID_EMIT for one finished strip (the arithmetic of the run-time tail above)
+    auto tail_resid = [&](int s, float v, float xp, float gp) {
+      const int n = s * 16 + c16;
+      const float xv = xp + v;
+      if (live) p.out[grow * p.ldo + n] = xv;
+      const float sqv = mul_rn(xv, xv);
+      float accs = sqv;
+#pragma unroll
+      for (int j = 1; j < 8; ++j) {
+        const float t = DIA_ROW_SHR(accs, 1);
+        if ((c16 & 7) == j) accs = add_rn(t, sqv);
+      }
+      const float h0 = DIA_ROW_SHR(accs, 8);
+      if (live && c16 == 15) p.ssq_out[(long)s * p.ssq_ld + grow] = h0 + accs;
+      stgf[ti * 256 + r16 * 16 + c16] = mul_rn(xv, gp);
+      lds_barrier();
+      if (tid < 128) {
+        const int tt = tid >> 6 & 1, u = tid & 63, mm_ = u >> 2, q = u & 3;
+        float* Pt = Pf + (long)(mt0 + tt) * p.p_ktiles * 512;
+        if (16 * tt + mm_ < Ml)
+          *reinterpret_cast<float4*>(Pt + plane_frag_off(mm_, s * 16 + (q >> 1) * 8, p.p_ktiles) + (q & 1) * 4) =
+              *reinterpret_cast<const float4*>(&stgf[tt * 256 + mm_ * 16 + q * 4]);
+      }
+      lds_barrier();                                        // the staging area is rewritten by the next strip
+    };
+    const __amdgpu_buffer_rsrc_t sr = agent_rsrc(p.sk_scratch);
+    for (; strip + G < p.nstrips; strip += 2 * G) {
+      const int sA = strip, sB = strip + G;
+      // residual and norm weight of strip B (A's were requested by the previous pair / the prologue)
+      const int nB = sB * 16 + c16;
+      const float xpB = p.out[(live ? grow : (long)16 * mt0) * p.ldo + nB], gpB = p.gnext[nB];
+      const float vA = mm(b0, b1, sB);
+      m4[ti * 256 + r16 * 16 + c16] = vA;
+      lds_barrier();                                        // red is rewritten by the second product
+      const float vB = mm(b1, b0, sB + G);
+      m4[512 + ti * 256 + r16 * 16 + c16] = vB;
+      lds_barrier();
+      // four partial tiles leave together: thread t < 256 carries floats 4t..4t+3 (strip t >> 7, tile (t >> 6) & 1, row (t & 63) >> 2)
+      const long uA = (long)blockIdx.z * p.nstrips + sA, uB = (long)blockIdx.z * p.nstrips + sB;
+      const int ps = tid >> 7, po = (tid & 127) * 4;
+      const long ub = ps ? uB : uA;
+      if (tid < 256) {
+        const float* f = &m4[ps * 512 + po];
+        st4_agent(sr, (int)(((ub * SK + ks) * 512 + po) * 4), f32x4{f[0], f[1], f[2], f[3]});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      lds_barrier();
+      if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(p.sk_tickets + uA, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lst = ticket == SK - 1;
+        if (lst) __hip_atomic_store(p.sk_tickets + uA, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        sk_flag = lst;
+      }
+      lds_barrier();
+      const bool last = sk_flag != 0;
+      if (last) {
+        if (tid < 256) {
+          f32x4 sv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < SK) sv[k] = ld4_agent(sr, (int)(((ub * SK + k) * 512 + po) * 4));
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < SK) { a[0] += sv[k][0]; a[1] += sv[k][1]; a[2] += sv[k][2]; a[3] += sv[k][3]; }
+          for (int k = 4; k < SK; ++k) {
+            const f32x4 t = ld4_agent(sr, (int)(((ub * SK + k) * 512 + po) * 4));
+            a[0] += t[0]; a[1] += t[1]; a[2] += t[2]; a[3] += t[3];
+          }
+          float* f = &m4[ps * 512 + po];
+          f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3];
+        }
+        lds_barrier();
+        tail_resid(sA, m4[ti * 256 + r16 * 16 + c16], xpre1, gpre1);
+        tail_resid(sB, m4[512 + ti * 256 + r16 * 16 + c16], xpB, gpB);
+      }
+      load_resid(DIA_PREFETCH_CLAMP(sA + 2 * G, p.nstrips));
+      lds_barrier();                                        // m4 / sk_flag are rewritten by the next pair
+    }
+    if (strip < p.nstrips) body(b0, b1, strip);
+    return;
+  }
   for (; strip + G < p.nstrips; strip += 2 * G) {
     body(b0, b1, strip);
     body(b1, b0, strip + G);
@@ -1838,6 +1948,7 @@ int dia_gemm_init() {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, false, 8, false, DIA_EPI_RESID_EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, false, 8, false, DIA_EPI_SWIGLU_EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, true, 8, false, -1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8, 8, true)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<4, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(4)) != hipSuccess) rc = 1;
@@ -2003,7 +2114,9 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
       const bool puni = !f32io && !a->cmap && !a->strip_map && (a->epi != DIA_EPI_RESID_EMIT || a->gnext) && dia_tune(DIA_TUNE_GEMM_2T) != 5;
       if (f32io) {
         const bool uni = dia_tune(DIA_TUNE_GEMM_2T) != 5;      // (knob 5: the run-time epilogue, A/B)
-        if (sk > 1) launch_small_kernel<k_gemm2t<8, true, true>>(grid, blk, g2t_smem(8), st, k);
+        if (sk > 1 && sk <= 4 && a->epi == DIA_EPI_RESID_EMIT && a->gnext && dia_tune(DIA_TUNE_GEMM_2T) != 6)     // (knob 6: one hand-off per strip, A/B)
+          launch_small_kernel<k_gemm2t<8, true, true, 8, false, -1, true>>(grid, blk, g2t_smem(8, 8, true), st, k);
+        else if (sk > 1) launch_small_kernel<k_gemm2t<8, true, true>>(grid, blk, g2t_smem(8), st, k);
         else if (uni && a->epi == DIA_EPI_SCALE_STORE) launch_small_kernel<k_gemm2t<8, true, false, 8, false, DIA_EPI_SCALE_STORE>>(grid, blk, g2t_smem(8), st, k);
         else if (uni && a->epi == DIA_EPI_RESID_EMIT) launch_small_kernel<k_gemm2t<8, true, false, 8, false, DIA_EPI_RESID_EMIT>>(grid, blk, g2t_smem(8), st, k);
         else if (uni && a->epi == DIA_EPI_SWIGLU_EMIT) launch_small_kernel<k_gemm2t<8, true, false, 8, false, DIA_EPI_SWIGLU_EMIT>>(grid, blk, g2t_smem(8), st, k);
