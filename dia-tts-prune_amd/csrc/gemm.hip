@@ -892,7 +892,7 @@ __global__ __launch_bounds__(1024) void k_gemv_diag(GemmK p) {
 // the compaction maps: the short-prompt prefill, 33..128 rows).
 // NW = 4 (planes, K = 1024 as 4 waves x 8 k-tiles, 256 threads, 74 KB of LDS): TWO workgroups per CU — the planes tail is 32 threads
 // per tile between two barriers, and with one workgroup per CU nothing else runs meanwhile (13.9 us per launch at 98 rows for 8-17 MB).
-constexpr size_t g2t_smem(int kpw, int nw = 8, bool sk2 = false) { return (size_t)2 * nw * kpw * 64 * 16 + sizeof(f32x4) * 2 * nw * 64 + 2 * 1024 + sizeof(float) * 32 + (sk2 ? 4096 : 0); }
+constexpr size_t g2t_smem(int kpw, int nw = 8, bool sk2 = false) { return (size_t)2 * nw * kpw * 64 * 16 + sizeof(f32x4) * 2 * nw * 64 + 2 * 1024 + sizeof(float) * 32 + (sk2 ? 8192 : 0); }
 // CKV (NW = 4, bf16 caches with the blocked V layout, no strip map): the cross-K/V tail on ALL 256 threads with UNCONDITIONAL stores.  vmcnt counts
 // stores as well as loads and retires in order; the wait before a strip's first MFMA is one static count for every wave, so it is the
 // count of the path that issued the FEWEST memory operations since the awaited load — with the tail on two of the waves (or behind
@@ -905,7 +905,7 @@ __device__ bf16_raw g_ckv_sink[1024];
 // run-time branches (`if (live)`, `if (tid < 128)`, the epilogue kind) the one static wait in front of the next strip's MFMAs is the count of the
 // emptiest path, and every wave that did store sits out the acknowledgement of its stores.  EPI = -1: the epilogue kind at run time (planes, split-K).
 __device__ float4 g_sink16[1024];
-// SK2 (fp32 tiles, split-K, RESID_EMIT = wo at 17..128 rows): the hand-off of the K quarters once per PAIR of strips — four partial tiles, one slab
+// SK2 (fp32 tiles, split-K, RESID_EMIT = wo at 17..128 rows): the hand-off of the K quarters once per GROUP of four (then two) strips — eight or four partial tiles, one slab
 // publication, one ticket, one merge.  A hand-off is two dependent coherent round trips (slab stores acknowledged, then the ticket) that nothing
 // overlaps: priced with a build that skips it, 13 of wo's 37 us at 128 rows (eight per workgroup).  Same slabs, same summation order: bit-identical.
 template <int KPW, bool AF32, bool SPLITK, int NW = 8, bool CKV = false, int EPI = -1, bool SK2 = false>
@@ -923,7 +923,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw + (size_t)2 * NW * KPW * 64 * 16);             // [2 tiles][NW][64]
   float* stgf = reinterpret_cast<float*>(smem_raw + (size_t)2 * NW * KPW * 64 * 16 + sizeof(f32x4) * 2 * NW * 64);   // [2 tiles][16][16]
   float* inv_s = stgf + 2 * 256;                                                               // [32]
-  [[maybe_unused]] float* m4 = inv_s + 32;                                                     // SK2: [2 strips][2 tiles][16][16]
+  [[maybe_unused]] float* m4 = inv_s + 32;                                                     // SK2: [4 strips][2 tiles][16][16]
+  [[maybe_unused]] const bool dia_sk2_quads = p.sk2_quads != 0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int mtiles = (p.M + 15) >> 4;
   const int mt0 = 2 * blockIdx.z;                          // first m-tile of this workgroup
@@ -1469,37 +1470,43 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
       lds_barrier();                                        // the staging area is rewritten by the next strip
     };
     const __amdgpu_buffer_rsrc_t sr = agent_rsrc(p.sk_scratch);
-    for (; strip + G < p.nstrips; strip += 2 * G) {
-      const int sA = strip, sB = strip + G;
-      // residual and norm weight of strip B (A's were requested by the previous pair / the prologue)
-      const int nB = sB * 16 + c16;
-      const float xpB = p.out[(live ? grow : (long)16 * mt0) * p.ldo + nB], gpB = p.gnext[nB];
-      const float vA = mm(b0, b1, sB);
-      m4[ti * 256 + r16 * 16 + c16] = vA;
-      lds_barrier();                                        // red is rewritten by the second product
-      const float vB = mm(b1, b0, sB + G);
-      m4[512 + ti * 256 + r16 * 16 + c16] = vB;
-      lds_barrier();
-      // four partial tiles leave together: thread t < 256 carries floats 4t..4t+3 (strip t >> 7, tile (t >> 6) & 1, row (t & 63) >> 2)
-      const long uA = (long)blockIdx.z * p.nstrips + sA, uB = (long)blockIdx.z * p.nstrips + sB;
+    // N = 4 or 2 strips (even: the two weight buffers alternate, the next group starts in b0 again) -> one hand-off
+    auto group = [&](auto n_tag) {
+      constexpr int N = decltype(n_tag)::value;
+      float xp[N], gp[N];
+      xp[0] = xpre1; gp[0] = gpre1;                         // (requested by the previous group / the prologue)
+#pragma unroll
+      for (int j = 1; j < N; ++j) {
+        const int n = (strip + j * G) * 16 + c16;
+        xp[j] = p.out[(live ? grow : (long)16 * mt0) * p.ldo + n];
+        gp[j] = p.gnext[n];
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float v = (j & 1) ? mm(b1, b0, strip + (j + 1) * G) : mm(b0, b1, strip + (j + 1) * G);
+        m4[j * 512 + ti * 256 + r16 * 16 + c16] = v;
+        lds_barrier();                                      // red is rewritten by the next product
+      }
+      // 2 N partial tiles leave together: thread t carries floats 4t..4t+3 of strip t >> 7 (tile (t >> 6) & 1, row (t & 63) >> 2)
       const int ps = tid >> 7, po = (tid & 127) * 4;
-      const long ub = ps ? uB : uA;
-      if (tid < 256) {
+      const long u0 = (long)blockIdx.z * p.nstrips + strip;
+      const long ub = u0 + (long)ps * G;
+      if (ps < N) {
         const float* f = &m4[ps * 512 + po];
         st4_agent(sr, (int)(((ub * SK + ks) * 512 + po) * 4), f32x4{f[0], f[1], f[2], f[3]});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       lds_barrier();
       if (tid == 0) {
-        const int ticket = __hip_atomic_fetch_add(p.sk_tickets + uA, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ticket = __hip_atomic_fetch_add(p.sk_tickets + u0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int lst = ticket == SK - 1;
-        if (lst) __hip_atomic_store(p.sk_tickets + uA, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        if (lst) __hip_atomic_store(p.sk_tickets + u0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         sk_flag = lst;
       }
       lds_barrier();
       const bool last = sk_flag != 0;
       if (last) {
-        if (tid < 256) {
+        if (ps < N) {
           f32x4 sv[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k)
@@ -1516,12 +1523,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
           f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3];
         }
         lds_barrier();
-        tail_resid(sA, m4[ti * 256 + r16 * 16 + c16], xpre1, gpre1);
-        tail_resid(sB, m4[512 + ti * 256 + r16 * 16 + c16], xpB, gpB);
+#pragma unroll
+        for (int j = 0; j < N; ++j) tail_resid(strip + j * G, m4[j * 512 + ti * 256 + r16 * 16 + c16], xp[j], gp[j]);
       }
-      load_resid(DIA_PREFETCH_CLAMP(sA + 2 * G, p.nstrips));
-      lds_barrier();                                        // m4 / sk_flag are rewritten by the next pair
-    }
+      load_resid(DIA_PREFETCH_CLAMP(strip + N * G, p.nstrips));
+      lds_barrier();                                        // m4 / sk_flag are rewritten by the next group
+      strip += N * G;
+    };
+    if (dia_sk2_quads)
+      while (strip + 3 * G < p.nstrips) group(std::integral_constant<int, 4>{});
+    while (strip + G < p.nstrips) group(std::integral_constant<int, 2>{});
     if (strip < p.nstrips) body(b0, b1, strip);
     return;
   }

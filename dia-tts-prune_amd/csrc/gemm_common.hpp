@@ -60,6 +60,7 @@ struct GemmK {
   int a_f32, p_f32;                        // A / P are fp32 activation tiles (common.hpp) instead of three bf16 planes
   long kv_plane_stride;                    // CROSSKV, DIA_KV_BF16X2
   long kv_layer_stride; int kv_layer_strips;   // CROSSKV over several layers (dia_gemm_args)
+  int sk2_quads;                                // k_gemm2t SK2: groups of four strips per hand-off (knob gemm_2t=7: pairs only)
   int w_planes; long w_plane_stride;       // k_gemm only: hi / mid / lo planes of fp32 weights, one tile set each
 };
 
@@ -376,6 +377,7 @@ inline int fill_gemmk(const dia_gemm_args* a, GemmK& k) {
   k.a_f32 = a->act_f32 & 1; k.p_f32 = (a->act_f32 >> 1) & 1;
   k.kv_plane_stride = a->kv_plane_stride;
   k.kv_layer_strips = a->kv_layer_strips; k.kv_layer_stride = a->kv_layer_stride;
+  k.sk2_quads = dia_tune(DIA_TUNE_GEMM_2T) != 7;
   k.w_planes = a->w_planes > 1 ? a->w_planes : 1; k.w_plane_stride = (long)a->KT * a->nstrips * 512;
   return DIA_OK;
 }
