@@ -914,7 +914,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
   static_assert(NW == 8 || (NW == 4 && !AF32 && !SPLITK), "the 256-thread form serves the planes path without split-K");
   static_assert(!CKV || (NW == 4 && KPW == 8), "the all-thread cross-K/V tail belongs to the 256-thread form");
   static_assert(EPI < 0 || (!SPLITK && !CKV && (NW == 8 || (!AF32 && EPI != DIA_EPI_RESID_EMIT))), "the uniform tails: no split-K; 256 threads only for planes without the residual");
-  static_assert(!SK2 || (AF32 && SPLITK && NW == 8 && EPI < 0 && !CKV), "the strip-pair hand-off belongs to the split-K form over fp32 tiles");
+  static_assert(!SK2 || (SPLITK && NW == 8 && EPI < 0 && !CKV), "the grouped hand-off belongs to the split-K form");
   const int epi = EPI >= 0 ? EPI : a_epi;
   p.A = a_A; p.a_plane_stride = a_aps; p.W = a_W; p.KT = a_KT; p.M = a_M; p.epi = a_epi; p.nstrips = a_nstrips;
   p.out = a_out; p.ldo = a_ldo; p.gnext = a_gnext;
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
     ck_c = p.cos_t[o]; ck_s = p.sin_t[o];
   };
   if constexpr (CKV) load_cs_all(blockIdx.x);
-  else if constexpr (AF32 || EPI >= 0) { if (resid) load_resid(blockIdx.x); }
+  else if constexpr (AF32 || EPI >= 0 || SK2) { if (resid) load_resid(blockIdx.x); }
   else { if (resid && e_thread) load_resid8(blockIdx.x); if (ckv && e_thread) load_cs(blockIdx.x); }
   __builtin_amdgcn_sched_barrier(0);
   load_strip(b0, blockIdx.x);
@@ -1460,12 +1460,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
       if (live && c16 == 15) p.ssq_out[(long)s * p.ssq_ld + grow] = h0 + accs;
       stgf[ti * 256 + r16 * 16 + c16] = mul_rn(xv, gp);
       lds_barrier();
-      if (tid < 128) {
-        const int tt = tid >> 6 & 1, u = tid & 63, mm_ = u >> 2, q = u & 3;
-        float* Pt = Pf + (long)(mt0 + tt) * p.p_ktiles * 512;
-        if (16 * tt + mm_ < Ml)
-          *reinterpret_cast<float4*>(Pt + plane_frag_off(mm_, s * 16 + (q >> 1) * 8, p.p_ktiles) + (q & 1) * 4) =
-              *reinterpret_cast<const float4*>(&stgf[tt * 256 + mm_ * 16 + q * 4]);
+      if constexpr (AF32) {
+        if (tid < 128) {
+          const int tt = tid >> 6 & 1, u = tid & 63, mm_ = u >> 2, q = u & 3;
+          float* Pt = Pf + (long)(mt0 + tt) * p.p_ktiles * 512;
+          if (16 * tt + mm_ < Ml)
+            *reinterpret_cast<float4*>(Pt + plane_frag_off(mm_, s * 16 + (q >> 1) * 8, p.p_ktiles) + (q & 1) * 4) =
+                *reinterpret_cast<const float4*>(&stgf[tt * 256 + mm_ * 16 + q * 4]);
+        }
+      } else if (tid < 192) {                               // planes: 2 tiles x 16 rows x 2 halves x 3 planes, one 16-byte fragment each
+        const int pl = tid >> 6, tt = (tid >> 5) & 1, mm_ = (tid >> 1) & 15, hf = tid & 1;
+        if (16 * tt + mm_ < Ml) {
+          const float* src = &stgf[tt * 256 + mm_ * 16 + hf * 8];
+          bf16x8 h, mi, lo;
+          split3x8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4), h, mi, lo);
+          *reinterpret_cast<bf16x8*>(p.P + (long)pl * p.p_plane_stride + (long)(mt0 + tt) * p.p_ktiles * 512 + plane_frag_off(mm_, s * 16 + hf * 8, p.p_ktiles)) =
+              pl == 0 ? h : (pl == 1 ? mi : lo);
+        }
       }
       lds_barrier();                                        // the staging area is rewritten by the next strip
     };
@@ -1533,7 +1544,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gemm2t(const bf16_
     if (dia_sk2_quads)
       while (strip + 3 * G < p.nstrips) group(std::integral_constant<int, 4>{});
     while (strip + G < p.nstrips) group(std::integral_constant<int, 2>{});
-    if (strip < p.nstrips) body(b0, b1, strip);
+    if (strip < p.nstrips) {
+      if constexpr (!AF32) { if (resid && e_thread) load_resid8(strip); }     // (the shared planes tail takes 8 residual values per thread)
+      body(b0, b1, strip);
+    }
     return;
   }
   for (; strip + G < p.nstrips; strip += 2 * G) {
@@ -1960,6 +1974,7 @@ int dia_gemm_init() {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, false, 8, false, DIA_EPI_SWIGLU_EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, true, true, 8, false, -1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8, 8, true)) != hipSuccess) rc = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, true, 8, false, -1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8, 8, true)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(8)) != hipSuccess) rc = 1;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2t<4, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2t_smem(4)) != hipSuccess) rc = 1;
@@ -2133,7 +2148,9 @@ extern "C" int dia_gemm(const dia_gemm_args* a, void* stream) {
         else if (uni && a->epi == DIA_EPI_SWIGLU_EMIT) launch_small_kernel<k_gemm2t<8, true, false, 8, false, DIA_EPI_SWIGLU_EMIT>>(grid, blk, g2t_smem(8), st, k);
         else launch_small_kernel<k_gemm2t<8, true, false>>(grid, blk, g2t_smem(8), st, k);
       } else if (ktw == 64) {
-        if (sk > 1) launch_small_kernel<k_gemm2t<8, false, true>>(grid, blk, g2t_smem(8), st, k);
+        if (sk > 1 && sk <= 4 && a->epi == DIA_EPI_RESID_EMIT && a->gnext && !a->cmap && dia_tune(DIA_TUNE_GEMM_2T) != 6)
+          launch_small_kernel<k_gemm2t<8, false, true, 8, false, -1, true>>(grid, blk, g2t_smem(8, 8, true), st, k);
+        else if (sk > 1) launch_small_kernel<k_gemm2t<8, false, true>>(grid, blk, g2t_smem(8), st, k);
         else if (puni && a->epi == DIA_EPI_RESID_EMIT) launch_small_kernel<k_gemm2t<8, false, false, 8, false, DIA_EPI_RESID_EMIT>>(grid, blk, g2t_smem(8), st, k);
         else launch_small_kernel<k_gemm2t<8, false, false>>(grid, blk, g2t_smem(8), st, k);
       } else if (half && a->epi == DIA_EPI_CROSSKV && a->kv_dtype == DIA_KV_BF16 && a->kv_vblocked && !a->strip_map && dia_tune(DIA_TUNE_GEMM_2T) != 4) {
