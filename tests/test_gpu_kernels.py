@@ -1282,3 +1282,54 @@ def test_gemm_crosskv_layers_merged_equals_per_layer(kvd, lens):
         got = k2[NL - 1, b0, :, : lens[b0]].double().transpose(0, 1)
         tol = 2e-5 if kvd == "f32" else 1e-2
         assert (got - kr).abs().max().item() <= tol * kr.abs().max().item()
+
+
+@pytest.mark.parametrize("M,K,D,sk,f32", [(128, 8192, 2048, 4, 1), (100, 8192, 2048, 4, 1), (64, 8192, 2048, 4, 1), (32, 8192, 2048, 4, 1),
+                                          (98, 4096, 1024, 2, 0), (128, 4096, 1024, 2, 0), (40, 8192, 1024, 4, 0)])
+def test_gemm2t_grouped_handoff_equals_per_strip(M, K, D, sk, f32):
+    """k_gemm2t split-K: the K slices handed over once per group of four / two strips (SK2) against once per strip (knob gemm_2t=6) and
+    against pairs only (knob 7): same bits in x, the sums of squares and the emitted activations; tickets re-armed; float64 reference"""
+    d = dev()
+    torch.manual_seed(M + K + D + sk)
+    a = torch.randn(M, K, device=d)
+    W = bf16r(torch.randn(K, D, device=d) * 0.02)
+    Wt, kt, ns = lay.tile_weight(W)
+    mpad = (M + 15) // 16 * 16
+    mt = mpad // 16
+    pkt = D // 32
+    gn = bf16r(1.0 + 0.1 * torch.randn(D, device=d))
+    x0 = torch.randn(mpad, D, device=d)
+    res = []
+    try:
+        for knob in (6, 7, -1):
+            hb.set_tuning("gemm_2t", knob)
+            A = lay.pack_planes(a)
+            if f32:
+                A.view(torch.float32).reshape(-1)[: A[0].numel()] = lay.pack_f32_tiles(a).reshape(-1)
+            g = hb.GemmArgs()
+            g.A, g.a_plane_stride, g.a_ktiles, g.M = hb.ptr(A), A[0].numel(), A.shape[2], M
+            g.W, g.KT, g.nstrips, g.epi, g.act_f32 = hb.ptr(Wt), kt, ns, hb.EPI_RESID_EMIT, 3 * f32
+            xr = x0.clone()
+            P = torch.full((3, mt, pkt, 64, 8), 7.0, dtype=torch.bfloat16, device=d)
+            ssq = torch.zeros(ns, mpad, device=d)
+            g.ssq_ld, g.out, g.ldo, g.gnext = mpad, hb.ptr(xr), D, hb.ptr(gn)
+            g.P, g.p_plane_stride, g.p_ktiles, g.ssq_out = hb.ptr(P), P[0].numel(), pkt, hb.ptr(ssq)
+            scr = torch.zeros(mt * ns * sk * 256, device=d)
+            tk = torch.zeros(mt * ns, dtype=torch.int32, device=d)
+            g.sk, g.sk_scratch, g.sk_tickets, g.sk_scratch_floats = sk, hb.ptr(scr), hb.ptr(tk), scr.numel()
+            for _ in range(2):                           # twice: the tickets must come back to zero
+                xr.copy_(x0)
+                hb.check(hb.lib().dia_gemm(C.byref(g), None), "dia_gemm")
+            torch.cuda.synchronize()
+            assert (tk == 0).all()
+            res.append((xr.clone(), ssq.clone(), P.clone()))
+    finally:
+        hb.set_tuning("gemm_2t", -1)
+    for other in res[:2]:
+        assert torch.equal(other[0][:M], res[2][0][:M]) and torch.equal(other[1][:, :M], res[2][1][:, :M])
+        un = (lambda P_: lay.unpack_f32_tiles(P_.view(torch.float32).reshape(-1)[: mt * pkt * 512].reshape(mt, pkt, 64, 8), mpad, D)) if f32 \
+            else (lambda P_: lay.unpack_planes(P_, mpad, D))
+        assert torch.equal(un(other[2])[:M], un(res[2][2])[:M])
+    ref = x0[:M].double() + a.double() @ W.double()
+    assert (res[2][0][:M].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(res[2][0][M:], x0[M:])
