@@ -683,6 +683,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
       if (r_thread) { tile[r16 * 17 + c16] = v0; tile1[r16 * 17 + c16] = v1; }
       lds_barrier();
       const __amdgpu_buffer_rsrc_t sr = agent_rsrc(p.sk_scratch);
+#ifdef DIA_X_NOHANDOFF
+      if (ks != SK - 1) return;                           // TIMING ONLY: no slab, no ticket, no merge (wrong results)
+      finish(s0, v0, xpre1, gpre1);
+      lds_barrier();
+      finish(s1, v1, xpreB, gpreB);
+      return;
+#endif
       if (tid < 128) {
         const int tsel = tid >> 6, row = (tid & 63) >> 2, c4 = (tid & 3) * 4;
         const float* t = (tsel ? tile1 : tile) + row * 17 + c4;

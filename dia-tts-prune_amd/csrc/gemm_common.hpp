@@ -311,6 +311,9 @@ __device__ __forceinline__ bool splitk_combine(const GemmK& p, float* tile, int 
   const int SK = gridDim.y;
   if (SK == 1) return true;
   const int ks = blockIdx.y;
+#ifdef DIA_X_NOHANDOFF
+  return ks == SK - 1;                                            // TIMING ONLY: no slab, no ticket, no merge (wrong results)
+#endif
   // hand-off through device-coherent (sc1) accesses with explicit ordering, no cache-wide fences — see
   // attn_finish in attn.hip
   // 16-byte coherent accesses: 64 threads carry the 16 x 16 tile (one row quarter each)
