@@ -409,8 +409,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm16(const bf16_raw* a_A, long a_
     const float4* Af = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.A) + ((long)kt0 * 64 + alane) * 8);
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
+#ifdef DIA_X_NOA                                             /* TIMING ONLY: one k-tile of the image eight times (wrong results) */
+      a[i][0] = __builtin_bit_cast(bf16x8, Af[0]);
+      a[i][1] = __builtin_bit_cast(bf16x8, Af[1]);
+#else
       a[i][0] = __builtin_bit_cast(bf16x8, Af[(long)i * 128]);
       a[i][1] = __builtin_bit_cast(bf16x8, Af[(long)i * 128 + 1]);
+#endif
     }
     if constexpr (!ALDS_LATE) {
 #pragma unroll
